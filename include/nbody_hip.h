@@ -1,0 +1,146 @@
+/*
+ * nbody_hip.h — C ABI of the MI355X (gfx950) N-body force/integration backend.
+ *
+ * Drop-in boundary for the hot path of UoB-HPC/stdpar-nbody: the reference has no FFI; its seam is
+ * the L3 -> L2 edge where a step driver (run_all_pairs, src/all_pairs.h:52; run_bvh, src/bvh.h:327)
+ * issues one blocking stdpar algorithm per phase over the raw-pointer view System::state_t
+ * (src/system.h:41-50).  Each entry point below replaces exactly one of those stdpar call sites and
+ * takes the same view (`nbody_state`, pointers now in device memory), so a reference maintainer
+ * swaps `std::for_each(par_unseq, ...)` for one call (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.  Every function returns 0 on success
+ *    and a non-zero code on failure; nbody_last_error() returns the message (thread-local).
+ *    No exception crosses the boundary.
+ *  - All phase calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default
+ *    stream).  Ordering between phases is stream order.  nbody_stream_sync() / nbody_download()
+ *    are the blocking points.
+ *  - dtype: NBODY_F32 | NBODY_F64.  dim: 2 | 3.  Arrays use the reference layout: m is T[sz];
+ *    x, v, a, ao are vec<T,D>[...] = D contiguous T per body (src/vec.h:17-19), no padding.
+ *  - Sharding (multi-GPU all-pairs): a state owns target bodies [first, first+count).  m and x
+ *    always hold ALL sz bodies (sources); v, a, ao hold `count` records, record k = body first+k.
+ *    Single GPU: first = 0, count = sz.
+ *  - The library never falls back to a CPU path: without a usable HIP device every call fails.
+ */
+#ifndef NBODY_HIP_H
+#define NBODY_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NBODY_F32 0
+#define NBODY_F64 1
+
+#define NBODY_OK 0
+#define NBODY_ERR_ARG 1     /* bad argument (dtype/dim/null pointer/size) */
+#define NBODY_ERR_HIP 2     /* HIP runtime error, message has hipGetErrorString */
+#define NBODY_ERR_STATE 3   /* call sequence error (e.g. build_tree before hilbert_sort) */
+
+/* Device-pointer mirror of System<T,N>::state_t (src/system.h:41-50) plus the shard window. */
+typedef struct nbody_state {
+  void* m;         /* T[sz]            masses of all bodies                         */
+  void* x;         /* vec<T,D>[sz]     positions of all bodies                      */
+  void* v;         /* vec<T,D>[count]  velocities of owned bodies                   */
+  void* a;         /* vec<T,D>[count]  accelerations of owned bodies                */
+  void* ao;        /* vec<T,D>[count]  previous-step accelerations of owned bodies  */
+  double dt;       /* time step   (converted to T inside, as System::dt is T)       */
+  double c;        /* constant G  (System::constant)                                */
+  uint32_t sz;     /* total number of bodies (System::size, index_t = uint32_t)     */
+  uint32_t first;  /* first owned body                                              */
+  uint32_t count;  /* number of owned bodies                                        */
+  int32_t dtype;   /* NBODY_F32 | NBODY_F64                                         */
+  int32_t dim;     /* 2 | 3                                                         */
+} nbody_state;
+
+/* Last error message of the calling thread ("" if none). */
+const char* nbody_last_error(void);
+
+/* Library / device identification: writes e.g. "gfx950:sramecc+:xnack-" and the CU count. */
+int nbody_device_info(int device, char* arch_out, size_t arch_len, int* cu_count);
+
+/* ---- all-pairs ---------------------------------------------------------------------------------- */
+
+/* K1. Replaces all_pairs_force (src/all_pairs.h:14-27):
+ *   a[i] = c * sum_{j != i} m[j] * (x[j] - x[i]) / (pow(|x[j]-x[i]|^2, 3/2) + eps(T))
+ * for owned bodies i; sources j = 0..sz-1 staged through LDS tiles. */
+int nbody_all_pairs_force(const nbody_state* s, void* stream);
+
+/* K2. Replaces all_pairs_collapsed_force (src/all_pairs.h:29-50) with its INTENDED semantics
+ * (64-bit pair space, all D components; the reference wraps the pair count at 2^32 and drops
+ * component 2 — SURVEY §0.5):  a[i] <- (a[i] - ao[i]) + sum_{j != i} (c*m[j]) * (x[j]-x[i]) / dist3.
+ * One lane per ordered pair inside a (target-tile x source-tile) block, wavefront shuffle
+ * reduction over the source axis, one atomic add per target per block.  Single-GPU only
+ * (first = 0, count = sz). */
+int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream);
+
+/* K3. Replaces System::accelerate_step (src/system.h:52-60) for owned bodies:
+ *   x += dt*v + ((0.5*dt)*dt)*ao;  v += (0.5*dt)*(a + ao);  ao = a          (bit-exact, no FMA) */
+int nbody_accelerate_step(const nbody_state* s, void* stream);
+
+/* Tuning knob for K1 (does not change which pairs are summed, only the split of the source range
+ * over the waves of a block and hence the rounding order).  split in {0 (auto from sz), 1, 2, 4};
+ * targets_per_thread in {0 (auto), 1, 2}.  The auto choice depends on sz only — never on
+ * first/count — so results are bitwise independent of how bodies are sharded over GPUs. */
+int nbody_all_pairs_configure(int split, int targets_per_thread);
+
+/* ---- Hilbert BVH (src/bvh.h) ---------------------------------------------------------------------- */
+
+/* Tree + scratch storage; replaces bvh<T,N>::alloc / dealloc (src/bvh.h:147-172).
+ * nleafs = bit_ceil(n), nlevels = log2(nleafs), nnodes = 2^nlevels - 1.  n >= 2. */
+typedef struct nbody_bvh nbody_bvh;
+int  nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n);
+void nbody_bvh_destroy(nbody_bvh* t);
+
+/* K4. Replaces bounding_box (src/bvh.h:17-22): AABB of all x padded by +-10 eps, always containing
+ * the origin.  Result stays on the device for K5; nbody_bvh_get_bounding_box copies it out
+ * (blocking): xmin_out/xmax_out are T[dim] on the host. */
+int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* stream);
+int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xmax_out, void* stream);
+
+/* K5+K6. Replaces hilbert_sort (src/bvh.h:25-96): 64-bit Hilbert key per body from the K4 box,
+ * stable LSD radix sort of (key, index), then one gather that permutes m, x, v, a, ao IN PLACE
+ * (caller-visible, exactly like the reference). Requires first = 0, count = sz. */
+int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* stream);
+
+/* K7+K8. Replaces bvh::build_tree (src/bvh.h:175-244): leaf-parent level from body pairs, then one
+ * launch per level upward (monopoles, AABBs, widths; dead nodes have mass 0 and width 0). */
+int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* stream);
+
+/* K9. Replaces bvh::compute_force (src/bvh.h:246-324): stackless traversal per owned body with the
+ * opening test bw^2 < theta^2 * dist2 evaluated exactly as the reference does (no FMA). */
+int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, double theta, void* stream);
+
+/* Test/diagnostic read-back of BVH internals (blocking device->host copies).
+ * what: 0 keys u64[n] (pre-sort order) | 1 perm u32[n] (new -> old) | 2 node monopoles T[nnodes][D+1]
+ * (x..., mass) | 3 node widths T[nnodes] | 4 node boxes T[nnodes][2D] | 5 traversal counters
+ * u32[n][4] {node tests, leaf visits, monopole terms, body terms} (filled by
+ * nbody_bvh_compute_force only after nbody_bvh_enable_counters(t, 1)). */
+int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream);
+int nbody_bvh_enable_counters(nbody_bvh* t, int on);
+uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
+
+/* ---- owning context (device mirrors of a host System), used by the C++ CLI host ------------------ */
+
+typedef struct nbody_ctx nbody_ctx;
+/* Allocates device arrays for n bodies on `device` and a private stream. */
+int  nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int device);
+void nbody_destroy(nbody_ctx* ctx);
+/* Host -> device copy of the System arrays (T[n], vec<T,D>[n] x4) and the scalars dt, c. Blocking. */
+int  nbody_upload(nbody_ctx* ctx, const void* m, const void* x, const void* v, const void* a, const void* ao, double dt,
+                  double c);
+/* Device -> host; any pointer may be NULL to skip that array.  m too: bvh permutes it. Blocking. */
+int  nbody_download(nbody_ctx* ctx, void* m, void* x, void* v, void* a, void* ao);
+/* The device view and stream of the context, to pass to the phase calls above. */
+int  nbody_ctx_state(nbody_ctx* ctx, nbody_state* out);
+void* nbody_ctx_stream(nbody_ctx* ctx);
+/* Blocks until all work queued on `stream` has completed (so wall-clock phase timers are honest). */
+int  nbody_stream_sync(void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY_HIP_H */

@@ -1,0 +1,291 @@
+"""Python host-side mirror of the reference's step-driver interface over the gfx950 backend.
+
+This module is PLUMBING: it binds the C ABI of libnbody_hip.so (include/nbody_hip.h) with ctypes and
+exposes the same phase calls the reference's drivers make (run_all_pairs, src/all_pairs.h:52-106;
+run_bvh, src/bvh.h:327-418).  All arithmetic happens in the HIP kernels; there is NO CPU fallback —
+if the shared library or a HIP device is missing every entry point raises.
+
+The directory name contains a hyphen, so import it with the loader in `tests/conftest.py`,
+`bench.py` or `__graft_entry__.py` (importlib by path, module name `stdpar_nbody_amd`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libnbody_hip.so")
+HOST_LIB_PATH = os.path.join(HERE, "libnbody_host.so")
+
+F32, F64 = 0, 1
+UNIFORM, PLUMMER, GALAXY = 0, 1, 2
+WORKLOADS = {"uniform": UNIFORM, "plummer": PLUMMER, "galaxy": GALAXY}
+
+
+class NbodyError(RuntimeError):
+    pass
+
+
+class nbody_state(C.Structure):
+    """include/nbody_hip.h: device-pointer mirror of System<T,N>::state_t (src/system.h:41-50)."""
+    _fields_ = [("m", C.c_void_p), ("x", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("ao", C.c_void_p),
+                ("dt", C.c_double), ("c", C.c_double), ("sz", C.c_uint32), ("first", C.c_uint32), ("count", C.c_uint32),
+                ("dtype", C.c_int32), ("dim", C.c_int32)]
+
+
+def build(verbose=False):
+    """Compile libnbody_hip.so (hipcc --offload-arch=gfx950), libnbody_host.so and the CLI, in-tree."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", HERE, "all"], stdout=out)
+
+
+# every symbol include/nbody_hip.h declares (tests/test_abi.py checks the .so exports them all)
+ABI_SYMBOLS = [
+    "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
+    "nbody_accelerate_step", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
+    "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
+    "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_nnodes", "nbody_create",
+    "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
+]
+
+_lib = None
+_host = None
+
+
+def lib():
+    """Load libnbody_hip.so; raises NbodyError when it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NbodyError(f"{LIB_PATH} is missing: run `make -C stdpar-nbody_amd` (or __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.nbody_last_error.restype = C.c_char_p
+        L.nbody_ctx_stream.restype = C.c_void_p
+        L.nbody_bvh_nnodes.restype = C.c_uint32
+        _lib = L
+    return _lib
+
+
+def host_lib():
+    """libnbody_host.so: the product's ISO-C++ workload generators (host/models.hpp) behind a C entry."""
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB_PATH):
+            raise NbodyError(f"{HOST_LIB_PATH} is missing: run `make -C stdpar-nbody_amd host`")
+        H = C.CDLL(HOST_LIB_PATH)
+        H.nbody_host_build_model.restype = C.c_int64
+        _host = H
+    return _host
+
+
+def _check(rc):
+    if rc != 0:
+        raise NbodyError(f"nbody backend error {rc}: {lib().nbody_last_error().decode()}")
+
+
+def np_dtype(dtype):
+    return np.float32 if dtype == F32 else np.float64
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def device_info(device=0):
+    arch = C.create_string_buffer(128)
+    cus = C.c_int()
+    _check(lib().nbody_device_info(device, arch, C.c_size_t(128), C.byref(cus)))
+    return arch.value.decode(), cus.value
+
+
+def configure_all_pairs(split=0, targets_per_thread=0):
+    _check(lib().nbody_all_pairs_configure(split, targets_per_thread))
+
+
+class HostSystem:
+    """Host arrays of the reference's System<T,N> (src/system.h:13-19)."""
+
+    def __init__(self, dtype, dim, n):
+        t = np_dtype(dtype)
+        self.dtype, self.dim, self.n = dtype, dim, n
+        self.m = np.zeros(n, t)
+        self.x = np.zeros((n, dim), t)
+        self.v = np.zeros((n, dim), t)
+        self.a = np.zeros((n, dim), t)
+        self.ao = np.zeros((n, dim), t)
+        self.dt = 0.0
+        self.c = 0.0
+
+
+def build_model(dtype, dim, workload, n):
+    """Product workload generators (host/models.hpp, mirrors src/models.h). Returns a HostSystem."""
+    wl = WORKLOADS[workload] if isinstance(workload, str) else workload
+    s = HostSystem(dtype, dim, n)
+    dt, c = C.c_double(), C.c_double()
+    sz = host_lib().nbody_host_build_model(dtype, dim, wl, C.c_uint32(n), _p(s.m), _p(s.x), _p(s.v), C.byref(dt), C.byref(c))
+    if sz < 0:
+        raise NbodyError(f"nbody_host_build_model failed ({sz})")
+    if sz != n:
+        t = HostSystem(dtype, dim, int(sz))
+        t.m[:], t.x[:], t.v[:] = s.m[:sz], s.x[:sz], s.v[:sz]
+        s = t
+    s.dt, s.c = dt.value, c.value
+    return s
+
+
+class Bvh:
+    """bvh<T,N> (src/bvh.h:98-325) on the device."""
+
+    def __init__(self, dtype, dim, n):
+        self.h = C.c_void_p()
+        self.dtype, self.dim, self.n = dtype, dim, n
+        _check(lib().nbody_bvh_create(C.byref(self.h), dtype, dim, C.c_uint32(n)))
+        self.nnodes = int(lib().nbody_bvh_nnodes(self.h))
+
+    def close(self):
+        if self.h:
+            lib().nbody_bvh_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bounding_box(self, st, stream=None):
+        _check(lib().nbody_bvh_bounding_box(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def get_bounding_box(self, stream=None):
+        t = np_dtype(self.dtype)
+        lo, hi = np.zeros(self.dim, t), np.zeros(self.dim, t)
+        _check(lib().nbody_bvh_get_bounding_box(self.h, _p(lo), _p(hi), C.c_void_p(stream)))
+        return lo, hi
+
+    def hilbert_sort(self, st, stream=None):
+        _check(lib().nbody_bvh_hilbert_sort(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def build_tree(self, st, stream=None):
+        _check(lib().nbody_bvh_build_tree(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def compute_force(self, st, theta, stream=None):
+        _check(lib().nbody_bvh_compute_force(self.h, C.byref(st), C.c_double(theta), C.c_void_p(stream)))
+
+    def enable_counters(self, on=True):
+        _check(lib().nbody_bvh_enable_counters(self.h, 1 if on else 0))
+
+    def read(self, what, stream=None):
+        t = np_dtype(self.dtype)
+        shapes = {0: ((self.n,), np.uint64), 1: ((self.n,), np.uint32), 2: ((self.nnodes, self.dim + 1), t),
+                  3: ((self.nnodes,), t), 4: ((self.nnodes, 2 * self.dim), t), 5: ((self.n, 4), np.uint32)}
+        shape, dt = shapes[what]
+        out = np.zeros(shape, dt)
+        _check(lib().nbody_bvh_read(self.h, what, _p(out), C.c_size_t(out.nbytes), C.c_void_p(stream)))
+        return out
+
+
+class DeviceSystem:
+    """Owning device mirror of a System<T,N>; phase methods mirror the calls of the reference drivers."""
+
+    def __init__(self, dtype, dim, n, device=0):
+        self.h = C.c_void_p()
+        self.dtype, self.dim, self.n = dtype, dim, n
+        _check(lib().nbody_create(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
+        self.stream = lib().nbody_ctx_stream(self.h)
+        self._bvh = None
+
+    @classmethod
+    def from_host(cls, hs, device=0):
+        d = cls(hs.dtype, hs.dim, hs.n, device)
+        d.upload(hs)
+        return d
+
+    def close(self):
+        if self._bvh is not None:
+            self._bvh.close()
+            self._bvh = None
+        if self.h:
+            lib().nbody_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, hs):
+        for k in ("m", "x", "v", "a", "ao"):
+            arr = getattr(hs, k)
+            assert arr.flags["C_CONTIGUOUS"] and arr.dtype == np_dtype(self.dtype)
+        _check(lib().nbody_upload(self.h, _p(hs.m), _p(hs.x), _p(hs.v), _p(hs.a), _p(hs.ao), C.c_double(hs.dt), C.c_double(hs.c)))
+
+    def download(self, hs=None):
+        hs = hs or HostSystem(self.dtype, self.dim, self.n)
+        _check(lib().nbody_download(self.h, _p(hs.m), _p(hs.x), _p(hs.v), _p(hs.a), _p(hs.ao)))
+        st = self.state()
+        hs.dt, hs.c = st.dt, st.c
+        return hs
+
+    def state(self, first=0, count=None):
+        """Device view; (first, count) selects a shard of targets (v/a/ao pointers are offset to it)."""
+        st = nbody_state()
+        _check(lib().nbody_ctx_state(self.h, C.byref(st)))
+        if first or (count is not None and count != self.n):
+            count = self.n - first if count is None else count
+            esz = (4 if self.dtype == F32 else 8) * self.dim
+            st.first, st.count = first, count
+            st.v, st.a, st.ao = st.v + first * esz, st.a + first * esz, st.ao + first * esz
+        return st
+
+    def sync(self):
+        _check(lib().nbody_stream_sync(C.c_void_p(self.stream)))
+
+    # K1/K2/K3
+    def all_pairs_force(self, first=0, count=None):
+        st = self.state(first, count)
+        _check(lib().nbody_all_pairs_force(C.byref(st), C.c_void_p(self.stream)))
+
+    def all_pairs_collapsed_force(self):
+        st = self.state()
+        _check(lib().nbody_all_pairs_collapsed_force(C.byref(st), C.c_void_p(self.stream)))
+
+    def accelerate_step(self, first=0, count=None):
+        st = self.state(first, count)
+        _check(lib().nbody_accelerate_step(C.byref(st), C.c_void_p(self.stream)))
+
+    # K4..K9
+    @property
+    def bvh(self):
+        if self._bvh is None:
+            self._bvh = Bvh(self.dtype, self.dim, self.n)
+        return self._bvh
+
+    def bvh_force(self, theta):
+        """One force phase of run_bvh (src/bvh.h:382-393)."""
+        st, b = self.state(), self.bvh
+        b.bounding_box(st, self.stream)
+        b.hilbert_sort(st, self.stream)
+        b.build_tree(st, self.stream)
+        b.compute_force(st, theta, self.stream)
+
+
+def executed_steps(steps, csv_detailed, warmup=10):
+    """Step-count semantics of the reference drivers."""
+    return steps if csv_detailed else max(steps, warmup)
+
+
+def run(dev, algorithm, nsteps, theta=0.5):
+    """The step loop of run_all_pairs / run_bvh on the device."""
+    for _ in range(nsteps):
+        if algorithm == "all-pairs":
+            dev.all_pairs_force()
+        elif algorithm == "all-pairs-collapsed":
+            dev.all_pairs_collapsed_force()
+        elif algorithm == "bvh":
+            dev.bvh_force(theta)
+        else:
+            raise ValueError(algorithm)
+        dev.accelerate_step()
+    dev.sync()

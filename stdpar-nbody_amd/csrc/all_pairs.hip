@@ -1,0 +1,379 @@
+// K1 all-pairs force, K2 all-pairs-collapsed force, K3 leapfrog step — hand-written for gfx950.
+//
+// K1 (replaces src/all_pairs.h:14-27).  Bound: FP64/FP32 VALU issue (no MFMA: the inner body is
+// sub/FMA/rsq/rcp, not a contraction).  Structure:
+//   * one lane per target body (R targets per lane), targets of a block held in VGPRs;
+//   * sources stream through LDS in tiles of TJ packed (x, m) records, staged by all 256 lanes with a
+//     register prefetch of the next tile so global latency hides under the current tile's math;
+//   * the source range of every tile is split over the JS waves that share a target group, so a
+//     small shard (N/8 bodies on one GPU) still puts >= 4 waves on every SIMD — one wave alone
+//     reaches only 75% of the FP64 issue rate (profiles/r01_valu_rates_microbench.txt);
+//   * wave partials are combined through LDS in a fixed order, so the result is deterministic and
+//     independent of how bodies are sharded over GPUs.
+//
+// K2 (replaces src/all_pairs.h:29-50, intended semantics).  Lanes run along the SOURCE axis (one
+// ordered pair per lane and step), each wave owns 64 targets whose positions it broadcasts with
+// v_readlane; the per-target partial over 64*KJ sources is reduced across the wavefront with
+// __shfl_xor, lane t keeps target t's sum, and after the tile each wave issues D coalesced atomic
+// adds.  grid.y splits the source range so small N still fills the chip.
+//
+// K3 (replaces src/system.h:52-60).  Pure HBM stream (7*D*sizeof(T) bytes/body), flat elementwise
+// over count*D scalars, FP contraction off so it is bit-identical to the reference's x86 -O2 build.
+#include "common.hpp"
+
+namespace nbody {
+
+constexpr int kBlock = 256;  // 4 waves
+constexpr int kWaves = kBlock / 64;
+constexpr int kTileJ = 512;  // sources per LDS tile (fixed: the rounding order depends on it)
+
+struct ap_config {
+  int split = 0;  // 0 = auto
+  int tpt   = 0;  // targets per thread, 0 = auto
+};
+static ap_config g_ap_config;
+
+// ------------------------------------------------------------------------------------------------
+// K1
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int R, int JS>
+__global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __restrict__ m, const T* __restrict__ x,
+                                                                 T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                                                 uint32_t count) {
+  using rec_t = src_rec<T, D>;
+  constexpr int TG  = kWaves / JS;    // target groups per block
+  constexpr int TB  = TG * 64 * R;    // targets per block
+  constexpr int LPT = kTileJ / kBlock;  // source records each lane stages per tile
+  constexpr int SUB = kTileJ / JS;    // sources of a tile handled by one wave
+
+  __shared__ rec_t tile[kTileJ];
+  __shared__ T partial[(JS > 1) ? (JS - 1) * TG * 64 * R * D : 1];
+
+  const int lane   = threadIdx.x & 63;
+  const int wave   = threadIdx.x >> 6;
+  const int tgroup = wave / JS;
+  const int jpart  = wave % JS;
+
+  // targets of this lane
+  T xi[R][D], acc[R][D];
+  uint32_t ti[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t local = blockIdx.x * TB + tgroup * (64 * R) + r * 64 + lane;
+    ti[r]          = local;
+    uint64_t i     = uint64_t(first) + (local < count ? local : 0u);  // clamp: out-of-range lanes compute, never store
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      xi[r][k]  = x[i * D + k];
+      acc[r][k] = T(0);
+    }
+  }
+
+  const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
+
+  // register staging of one tile: LPT records per lane
+  rec_t stage[LPT];
+  auto stage_load = [&](uint32_t t) {
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) {
+      uint64_t j = uint64_t(t) * kTileJ + q * kBlock + threadIdx.x;
+      if (j < sz) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) stage[q].p[k] = x[j * D + k];
+        stage[q].m = m[j];
+      } else {  // padding: zero mass contributes exactly 0
+#pragma unroll
+        for (int k = 0; k < D; ++k) stage[q].p[k] = T(0);
+        stage[q].m = T(0);
+      }
+      if (D == 2) stage[q].p[2] = T(0);
+    }
+  };
+
+  stage_load(0);
+  for (uint32_t t = 0; t < ntiles; ++t) {
+    __syncthreads();  // every wave is done reading the previous tile
+#pragma unroll
+    for (int q = 0; q < LPT; ++q) tile[q * kBlock + threadIdx.x] = stage[q];
+    __syncthreads();
+    if (t + 1 < ntiles) stage_load(t + 1);  // in flight while this tile is consumed
+
+    const rec_t* src = &tile[jpart * SUB];
+#pragma unroll 4
+    for (int jj = 0; jj < SUB; ++jj) {
+      rec_t s = src[jj];  // wave-uniform address: LDS broadcast
+#pragma unroll
+      for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], s);
+    }
+  }
+
+  // combine the JS source-split partials in wave order, then a = c * sum
+  if constexpr (JS > 1) {
+    __syncthreads();
+    if (jpart > 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) partial[((((jpart - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane] = acc[r][k];
+    }
+    __syncthreads();
+    if (jpart == 0) {
+#pragma unroll
+      for (int p = 1; p < JS; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc[r][k] += partial[((((p - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane];
+    }
+  }
+  if (jpart == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (ti[r] < count) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[uint64_t(ti[r]) * D + k] = c * acc[r][k];
+      }
+    }
+  }
+}
+
+template <typename T, int D, int R, int JS>
+static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
+  constexpr int TB = (kWaves / JS) * 64 * R;
+  uint32_t blocks  = (s->count + TB - 1) / TB;
+  if (blocks == 0) return NBODY_OK;
+  hipLaunchKernelGGL((all_pairs_force_kernel<T, D, R, JS>), dim3(blocks), dim3(kBlock), 0, st, static_cast<const T*>(s->m),
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count);
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+// Source split: chosen from sz ONLY (never from first/count) so that every shard of a multi-GPU run
+// sums in the same order as the single-GPU run.
+static int auto_split(uint32_t sz) {
+  (void)sz;
+  return 4;
+}
+
+template <typename T, int D>
+static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
+  int js = g_ap_config.split ? g_ap_config.split : auto_split(s->sz);
+  int r  = g_ap_config.tpt;
+  if (r == 0) {
+    // enough waves to give every SIMD >= 8 with R = 2?  (1024 SIMDs; waves = count/64/R*JS)
+    uint64_t waves_r2 = (uint64_t(s->count) + 127) / 128 * js;
+    r                 = waves_r2 >= 8192 ? 2 : 1;
+  }
+#define NB_CASE(RR, JJ) \
+  if (r == RR && js == JJ) return launch_all_pairs<T, D, RR, JJ>(s, st)
+  NB_CASE(1, 1);
+  NB_CASE(1, 2);
+  NB_CASE(1, 4);
+  NB_CASE(2, 1);
+  NB_CASE(2, 2);
+  NB_CASE(2, 4);
+#undef NB_CASE
+  set_error("all-pairs: unsupported config split=%d targets_per_thread=%d", js, r);
+  return NBODY_ERR_ARG;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2
+// ------------------------------------------------------------------------------------------------
+constexpr int kColTileJ = 1024;  // sources per LDS tile (16 per lane)
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void collapsed_reset_kernel(T* __restrict__ a, const T* __restrict__ ao, uint64_t n) {
+  // diagonal pairs of the reference (src/all_pairs.h:35-40): a[i] -= ao[i]
+  uint64_t e = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < n) a[e] = a[e] - ao[e];
+}
+
+template <typename T>
+__device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T lane_bcast(T v, int src) {  // src is wave-uniform
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
+  } else {
+    long long b = __builtin_bit_cast(long long, v);
+    int lo      = __builtin_amdgcn_readlane(int(b), src);
+    int hi      = __builtin_amdgcn_readlane(int(b >> 32), src);
+    return __builtin_bit_cast(T, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __restrict__ m, const T* __restrict__ x,
+                                                                     T* __restrict__ a, T c, uint32_t sz,
+                                                                     uint32_t tiles_per_block) {
+  using rec_t = src_rec<T, D>;
+  constexpr int KJ = kColTileJ / 64;
+  __shared__ rec_t tile[kColTileJ];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+
+  // 64 targets per wave: lane l owns target i0 + l
+  const uint32_t i0   = (blockIdx.x * kWaves + wave) * 64;
+  const uint32_t imy  = i0 + lane;
+  const bool ivalid   = imy < sz;
+  T xt[D], mine[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xt[k]   = x[uint64_t(ivalid ? imy : 0u) * D + k];
+    mine[k] = T(0);
+  }
+  const int ntargets = (i0 < sz) ? int(min(64u, sz - i0)) : 0;  // wave-uniform
+
+  const uint32_t ntiles = (sz + kColTileJ - 1) / kColTileJ;
+  const uint32_t t0     = blockIdx.y * tiles_per_block;
+  const uint32_t t1     = min(ntiles, t0 + tiles_per_block);
+
+  for (uint32_t t = t0; t < t1; ++t) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kColTileJ / kBlock; ++q) {
+      uint32_t slot = q * kBlock + threadIdx.x;
+      uint64_t j    = uint64_t(t) * kColTileJ + slot;
+      rec_t r;
+      if (j < sz) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) r.p[k] = x[j * D + k];
+        r.m = m[j];
+      } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) r.p[k] = T(0);
+        r.m = T(0);
+      }
+      if (D == 2) r.p[2] = T(0);
+      tile[slot] = r;
+    }
+    __syncthreads();
+
+    // my KJ sources of this tile live in registers for all 64 targets of the wave
+    rec_t src[KJ];
+#pragma unroll
+    for (int q = 0; q < KJ; ++q) src[q] = tile[q * 64 + lane];
+
+    for (int tt = 0; tt < ntargets; ++tt) {
+      T xi[D], part[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        xi[k]   = lane_bcast(xt[k], tt);
+        part[k] = T(0);
+      }
+#pragma unroll
+      for (int q = 0; q < KJ; ++q) pair_accumulate<T, D>(part, xi, src[q]);
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        T tot = wave_sum(part[k]);
+        if (lane == tt) mine[k] += tot;
+      }
+    }
+  }
+
+  if (ivalid && t0 < t1) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) atomicAdd(&a[uint64_t(imy) * D + k], c * mine[k]);
+  }
+}
+
+template <typename T, int D>
+static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
+  NB_ARG(s->first == 0 && s->count == s->sz, "all-pairs-collapsed is single-GPU: needs first=0, count=sz");
+  if (s->sz == 0) return NBODY_OK;
+  uint64_t nelem = uint64_t(s->sz) * D;
+  hipLaunchKernelGGL((collapsed_reset_kernel<T, D>), dim3((nelem + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     static_cast<T*>(s->a), static_cast<const T*>(s->ao), nelem);
+  NB_HIP(hipGetLastError());
+  uint32_t iblocks = (s->sz + kWaves * 64 - 1) / (kWaves * 64);
+  uint32_t ntiles  = (s->sz + kColTileJ - 1) / kColTileJ;
+  // aim for >= 4096 blocks (16 per CU) while keeping >= 1 tile per block
+  uint32_t ysplit = (4096 + iblocks - 1) / iblocks;
+  if (ysplit > ntiles) ysplit = ntiles;
+  if (ysplit < 1) ysplit = 1;
+  if (ysplit > 65535) ysplit = 65535;
+  uint32_t tpb = (ntiles + ysplit - 1) / ysplit;
+  ysplit       = (ntiles + tpb - 1) / tpb;
+  hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
+                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
+                     s->sz, tpb);
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void accelerate_step_kernel(T* __restrict__ x, T* __restrict__ v, const T* __restrict__ a,
+                                                                 T* __restrict__ ao, T dt, uint64_t n) {
+#pragma clang fp contract(off)
+  const T hdt   = T(0.5) * dt;
+  const T hdtdt = hdt * dt;
+  for (uint64_t e = uint64_t(blockIdx.x) * kBlock + threadIdx.x; e < n; e += uint64_t(gridDim.x) * kBlock) {
+    T ae = a[e], aoe = ao[e], ve = v[e];
+    T t1 = dt * ve;
+    T t2 = hdtdt * aoe;
+    x[e] = x[e] + (t1 + t2);
+    v[e] = ve + hdt * (ae + aoe);
+    ao[e] = ae;
+  }
+}
+
+template <typename T, int D>
+static int accelerate_dispatch(const nbody_state* s, hipStream_t st) {
+  uint64_t n = uint64_t(s->count) * D;
+  if (n == 0) return NBODY_OK;
+  uint64_t blocks = (n + kBlock - 1) / kBlock;
+  if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride the rest
+  T* xloc = static_cast<T*>(s->x) + uint64_t(s->first) * D;
+  hipLaunchKernelGGL((accelerate_step_kernel<T>), dim3(uint32_t(blocks)), dim3(kBlock), 0, st, xloc, static_cast<T*>(s->v),
+                     static_cast<const T*>(s->a), static_cast<T*>(s->ao), static_cast<T>(s->dt), n);
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+}  // namespace nbody
+
+// ---- C ABI ------------------------------------------------------------------------------------------
+using namespace nbody;
+
+extern "C" int nbody_all_pairs_configure(int split, int targets_per_thread) {
+  NB_ARG(split == 0 || split == 1 || split == 2 || split == 4, "split must be 0, 1, 2 or 4 (got %d)", split);
+  NB_ARG(targets_per_thread >= 0 && targets_per_thread <= 2, "targets_per_thread must be 0, 1 or 2 (got %d)",
+         targets_per_thread);
+  g_ap_config.split = split;
+  g_ap_config.tpt   = targets_per_thread;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_all_pairs_force(const nbody_state* s, void* stream) {
+  if (int r = check_state(s)) return r;
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return all_pairs_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
+  });
+}
+
+extern "C" int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream) {
+  if (int r = check_state(s)) return r;
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return collapsed_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
+  });
+}
+
+extern "C" int nbody_accelerate_step(const nbody_state* s, void* stream) {
+  if (int r = check_state(s)) return r;
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return accelerate_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
+  });
+}

@@ -1,0 +1,834 @@
+// Hilbert-sorted BVH for gfx950 — K4 bounding box, K5 Hilbert keys, K6 radix sort + gather,
+// K7/K8 tree build, K9 stackless traversal.  Replaces src/bvh.h:17-325 of the reference.
+//
+// Data layout in HBM (per tree, sized by nbody_bvh_create):
+//   bbox      T[3*D]            xmin, xmax (K4) and the grid cell size (K5's divisor)
+//   keys[2]   u64[n] x2         ping-pong radix-sort key buffers
+//   idx[2]    u32[n] x2         ping-pong payload (original body index); the final one is the permutation
+//   hist      u32[256*nblk]     per-(digit, block) counts -> exclusive offsets
+//   tmp       T[n*(4D+1)]       gather scratch for the in-place permutation of m,x,v,a,ao
+//   node      rec[nnodes]       one power-of-two sized record per node: COM (D), mass, width.
+//                               The traversal touches exactly one record per node test (the reference
+//                               keeps m/bw/b in three arrays, src/bvh.h:103-106).
+//   box       T[nnodes*2D]      node AABBs, only used by the build
+// Everything integer (keys, sort, permutation, traversal decisions, node visit counts) is bit-exact
+// against the oracle; tree COMs/widths are bit-exact too (FP contraction is off in the build and in
+// the opening test), only the accumulated force uses the fast pair math of common.hpp.
+#include "common.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace nbody {
+
+constexpr int kB = 256;
+
+template <typename T, int D>
+struct alignas(((D + 2) * sizeof(T) <= 16) ? 16 : ((D + 2) * sizeof(T) <= 32 ? 32 : 64)) node_rec {
+  T p[D];
+  T mass;
+  T bw;
+};
+
+}  // namespace nbody
+
+struct nbody_bvh {
+  int dtype = 0, dim = 0;
+  uint32_t n = 0, nlevels = 0, nnodes = 0;
+  size_t tsz = 0, rec_bytes = 0;
+  uint32_t sort_blocks = 0, bbox_blocks = 0;
+  void* bbox      = nullptr;
+  void* partials  = nullptr;
+  uint64_t* keys[2] = {nullptr, nullptr};
+  uint32_t* idx[2]  = {nullptr, nullptr};
+  uint32_t* hist  = nullptr;
+  void* tmp       = nullptr;
+  void* node      = nullptr;
+  void* box       = nullptr;
+  uint32_t* counters = nullptr;
+  int final_buf   = 0;  // which idx[] holds the permutation after the sort
+  bool counters_on = false, have_bbox = false, sorted = false, built = false;
+};
+
+namespace nbody {
+
+// ------------------------------------------------------------------------------------------------
+// K4 bounding box  (src/bvh.h:17-22, src/vec.h:382-405)
+// min over i of fl(p_i - tol) == fl(min_i p_i - tol) (rounding is monotone), so the raw coordinates
+// are reduced and the +-10 eps pad is applied once; the origin is part of the reduction because the
+// reference's init value is the AABB of the origin.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T fmin_(T a, T b) {
+  if constexpr (sizeof(T) == 4) return __builtin_fminf(a, b);
+  else return __builtin_fmin(a, b);
+}
+template <typename T>
+__device__ __forceinline__ T fmax_(T a, T b) {
+  if constexpr (sizeof(T) == 4) return __builtin_fmaxf(a, b);
+  else return __builtin_fmax(a, b);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void block_minmax(T (&lo)[D], T (&hi)[D], T* out /* [2D] */) {
+  __shared__ T red[2 * D][kB / 64];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[k] = fmin_(lo[k], __shfl_xor(lo[k], off, 64));
+      hi[k] = fmax_(hi[k], __shfl_xor(hi[k], off, 64));
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      red[k][wave]     = lo[k];
+      red[D + k][wave] = hi[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T l = red[k][0], h = red[D + k][0];
+      for (int w = 1; w < kB / 64; ++w) {
+        l = fmin_(l, red[k][w]);
+        h = fmax_(h, red[D + k][w]);
+      }
+      out[k]     = l;
+      out[D + k] = h;
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void bbox_partial_kernel(const T* __restrict__ x, uint32_t n, T* __restrict__ partials) {
+  T lo[D], hi[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) lo[k] = hi[k] = T(0);
+  for (uint64_t i = uint64_t(blockIdx.x) * kB + threadIdx.x; i < n; i += uint64_t(gridDim.x) * kB) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T p   = x[i * D + k];
+      lo[k] = fmin_(lo[k], p);
+      hi[k] = fmax_(hi[k], p);
+    }
+  }
+  block_minmax<T, D>(lo, hi, partials + uint64_t(blockIdx.x) * 2 * D);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void bbox_final_kernel(const T* __restrict__ partials, uint32_t nblk, T* __restrict__ bbox) {
+#pragma clang fp contract(off)
+  __shared__ T res[2 * D];
+  T lo[D], hi[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) lo[k] = hi[k] = T(0);
+  for (uint32_t b = threadIdx.x; b < nblk; b += kB) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      lo[k] = fmin_(lo[k], partials[uint64_t(b) * 2 * D + k]);
+      hi[k] = fmax_(hi[k], partials[uint64_t(b) * 2 * D + D + k]);
+    }
+  }
+  block_minmax<T, D>(lo, hi, res);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // tol = epsilon * 10. evaluated in double then converted (src/vec.h:389)
+    const T tol          = T(double(sizeof(T) == 4 ? double(FLT_EPSILON) : DBL_EPSILON) * 10.);
+    const uint32_t cells = (D == 2) ? 0xffffffffu : 0x1fffffu;  // src/bvh.h:33
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T mn            = res[k] - tol;
+      T mx            = res[D + k] + tol;
+      bbox[k]         = mn;
+      bbox[D + k]     = mx;
+      bbox[2 * D + k] = (mx - mn) / T(cells);  // grid_cell_size (src/bvh.h:34), IEEE divide
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5 Hilbert keys  (src/bvh.h:33-45, src/vec.h:266-356)
+// ------------------------------------------------------------------------------------------------
+template <int D>
+__device__ __forceinline__ uint64_t interleave_bits(const uint32_t (&c)[D]) {
+  if constexpr (D == 2) {
+    auto split = [](uint64_t q) {
+      q = (q | q << 16) & 0xffff0000ffffull;
+      q = (q | q << 8) & 0xff00ff00ff00ffull;
+      q = (q | q << 4) & 0xf0f0f0f0f0f0f0full;
+      q = (q | q << 2) & 0x3333333333333333ull;
+      q = (q | q << 1) & 0x5555555555555555ull;
+      return q;
+    };
+    return split(c[1]) | (split(c[0]) << 1);
+  } else {
+    auto split = [](uint64_t q) {
+      q &= 0x1fffffull;
+      q = (q | q << 32) & 0x1f00000000ffffull;
+      q = (q | q << 16) & 0x1f0000ff0000ffull;
+      q = (q | q << 8) & 0x100f00f00f00f00full;
+      q = (q | q << 4) & 0x10c30c30c30c30c3ull;
+      q = (q | q << 2) & 0x1249249249249249ull;
+      return q;
+    };
+    return split(c[2]) | (split(c[1]) << 1) | (split(c[0]) << 2);
+  }
+}
+
+// Skilling's transform over dims 0 and 1 only — in 3D too (the reference sets n = 2 there,
+// src/vec.h:328) — with 32 (2D) or 21 (3D) bits; dim 2 is interleaved untransformed.
+template <int D>
+__device__ __forceinline__ uint64_t hilbert_key(uint32_t (&xx)[D]) {
+  constexpr uint32_t M = (D == 2) ? (1u << 31) : (1u << 20);
+  for (uint32_t Q = M; Q > 1; Q >>= 1) {
+    const uint32_t P = Q - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (xx[i] & Q) {
+        xx[0] ^= P;
+      } else {
+        uint32_t t = (xx[0] ^ xx[i]) & P;
+        xx[0] ^= t;
+        xx[i] ^= t;
+      }
+    }
+  }
+  xx[1] ^= xx[0];
+  uint32_t t = 0;
+  for (uint32_t Q = M; Q > 1; Q >>= 1)
+    if (xx[1] & Q) t ^= Q - 1;
+  xx[0] ^= t;
+  xx[1] ^= t;
+  return interleave_bits<D>(xx);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void hilbert_keys_kernel(const T* __restrict__ x, uint32_t n, const T* __restrict__ bbox,
+                                                          uint64_t* __restrict__ keys) {
+#pragma clang fp contract(off)
+  uint64_t i = uint64_t(blockIdx.x) * kB + threadIdx.x;
+  if (i >= n) return;
+  uint32_t cell[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    T q = (x[i * D + k] - bbox[k]) / bbox[2 * D + k];  // IEEE divide, as the reference
+    // cast<uint32_t> of an out-of-range value: x86-64 converts through 64 bits and keeps the low half
+    cell[k] = uint32_t(static_cast<long long>(q));
+  }
+  keys[i] = hilbert_key<D>(cell);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 stable LSD radix sort of (key, index), 8 bits per pass  (replaces std::sort, src/bvh.h:55-94;
+// the reference sort is unstable, ties here keep original index order)
+// ------------------------------------------------------------------------------------------------
+constexpr int kSortIPT  = 8;
+constexpr int kSortTile = kB * kSortIPT;  // 2048 keys per block; wave w owns keys [w*512, w*512+512)
+
+__global__ __launch_bounds__(kB) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                        uint32_t* __restrict__ hist, uint32_t nblk) {
+  __shared__ uint32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kSortIPT; ++q) {
+    uint64_t i = uint64_t(blockIdx.x) * kSortTile + q * kB + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// single-block exclusive scan over hist[total] (digit-major, block-minor)
+__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t total) {
+  __shared__ uint32_t wsum[16];
+  const uint32_t per = (total + 1023u) / 1024u;
+  const uint32_t b   = threadIdx.x * per;
+  const uint32_t e   = min(total, b + per);
+  uint32_t s         = 0;
+  for (uint32_t i = b; i < e; ++i) s += hist[i];
+  // inclusive scan of s across the block
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = s;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    uint32_t o = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < wave; ++w) base += wsum[w];
+  uint32_t run = base + inc - s;  // exclusive prefix of this thread's chunk
+  for (uint32_t i = b; i < e; ++i) {
+    uint32_t v = hist[i];
+    hist[i]    = run;
+    run += v;
+  }
+}
+
+__global__ __launch_bounds__(kB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                           uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                           uint32_t n, int shift, const uint32_t* __restrict__ hist,
+                                                           uint32_t nblk) {
+  __shared__ uint32_t wcnt[kB / 64][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = threadIdx.x; q < (kB / 64) * 256; q += kB) (&wcnt[0][0])[q] = 0;
+  __syncthreads();
+
+  uint64_t key[kSortIPT];
+  uint32_t pay[kSortIPT], rank[kSortIPT];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int s = 0; s < kSortIPT; ++s) {
+    uint64_t i       = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
+    const bool valid = i < n;
+    key[s]           = valid ? keys_in[i] : 0ull;
+    pay[s]           = valid ? (idx_in ? idx_in[i] : uint32_t(i)) : 0u;
+    const uint32_t d = uint32_t(key[s] >> shift) & 255u;
+    // lanes of this strip holding the same digit
+    uint64_t same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit      = (d >> b) & 1u;
+      const uint64_t vote = __ballot(valid && bit);
+      same &= bit ? vote : ~vote;
+    }
+    const uint32_t before = __popcll(same & lt_mask);
+    const uint32_t base   = wcnt[wave][d];
+    rank[s]               = base + before;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
+    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  // digit = threadIdx.x: turn per-wave counts into global bases
+  {
+    uint32_t run = hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kB / 64; ++w) {
+      uint32_t cw          = wcnt[w][threadIdx.x];
+      wcnt[w][threadIdx.x] = run;
+      run += cw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < kSortIPT; ++s) {
+    uint64_t i = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
+    if (i < n) {
+      const uint32_t d   = uint32_t(key[s] >> shift) & 255u;
+      const uint32_t pos = wcnt[wave][d] + rank[s];
+      keys_out[pos]      = key[s];
+      idx_out[pos]       = pay[s];
+    }
+  }
+}
+
+// gather all five state arrays through the permutation into tmp (then copied back)
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void gather_kernel(const uint32_t* __restrict__ perm, uint32_t n, const T* __restrict__ m,
+                                                    const T* __restrict__ x, const T* __restrict__ v, const T* __restrict__ a,
+                                                    const T* __restrict__ ao, T* __restrict__ tmp) {
+  uint64_t i = uint64_t(blockIdx.x) * kB + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t o = perm[i];
+  T* tx  = tmp;
+  T* tv  = tmp + uint64_t(n) * D;
+  T* ta  = tmp + uint64_t(n) * D * 2;
+  T* tao = tmp + uint64_t(n) * D * 3;
+  T* tm  = tmp + uint64_t(n) * D * 4;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    tx[i * D + k]  = x[o * D + k];
+    tv[i * D + k]  = v[o * D + k];
+    ta[i * D + k]  = a[o * D + k];
+    tao[i * D + k] = ao[o * D + k];
+  }
+  tm[i] = m[o];
+}
+
+// ------------------------------------------------------------------------------------------------
+// K7 / K8 tree build  (src/bvh.h:175-244)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__device__ __forceinline__ T node_width(const T* b) {  // src/bvh.h:140-144, std::max
+  T w = b[D] - b[0];
+#pragma unroll
+  for (int k = 1; k < D; ++k) {
+    T l = b[D + k] - b[k];
+    w   = (w < l) ? l : w;
+  }
+  return w;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restrict__ m, const T* __restrict__ x, uint32_t nbodies,
+                                                              uint32_t first, uint32_t count, node_rec<T, D>* __restrict__ node,
+                                                              T* __restrict__ box) {
+#pragma clang fp contract(off)
+  uint32_t li = blockIdx.x * kB + threadIdx.x;
+  if (li >= count) return;
+  const uint32_t i  = first + li;
+  const uint64_t bl = uint64_t(li) * 2, br = bl + 1;
+  const T tol = T(double(sizeof(T) == 4 ? double(FLT_EPSILON) : DBL_EPSILON) * 10.);
+  node_rec<T, D> r;
+  T* b = box + uint64_t(i) * 2 * D;
+  if (bl >= nbodies) {  // dead node (src/bvh.h:185-188); box/width are don't-care in the reference, 0 here
+#pragma unroll
+    for (int k = 0; k < D; ++k) r.p[k] = T(0);
+    r.mass = T(0);
+    r.bw   = T(0);
+#pragma unroll
+    for (int k = 0; k < 2 * D; ++k) b[k] = T(0);
+  } else if (br >= nbodies) {  // single body (src/bvh.h:190-194)
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T p      = x[bl * D + k];
+      r.p[k]   = p;
+      b[k]     = p - tol;
+      b[D + k] = p + tol;
+    }
+    r.mass = m[bl];
+    r.bw   = node_width<T, D>(b);
+  } else {  // two bodies (src/bvh.h:195-205)
+    const T ml = m[bl], mr = m[br];
+    const T mass = ml + mr;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      T p0 = x[bl * D + k], p1 = x[br * D + k];
+      T com    = ml * p0 + mr * p1;
+      r.p[k]   = com / mass;
+      b[k]     = fmin_(p0, p1) - tol;
+      b[D + k] = fmax_(p0, p1) + tol;
+    }
+    r.mass = mass;
+    r.bw   = node_width<T, D>(b);
+  }
+  node[i] = r;
+}
+
+// Levels [l_hi ... l_lo] (descending), one launch.  Levels with more than one block's worth of nodes
+// are launched one per kernel (l_hi == l_lo); the top of the tree (<= kB nodes per level) is built
+// by a single block looping over levels with a barrier in between.
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_lo, node_rec<T, D>* __restrict__ node,
+                                                                T* __restrict__ box) {
+#pragma clang fp contract(off)
+  for (int l = l_hi; l >= l_lo; --l) {
+    const uint32_t first = (1u << l) - 1u, count = 1u << l;
+    for (uint32_t li = blockIdx.x * kB + threadIdx.x; li < count; li += gridDim.x * kB) {
+      const uint32_t i  = first + li;
+      const uint32_t bl = li * 2 + first + count, br = bl + 1;
+      const node_rec<T, D> ml = node[bl];
+      const node_rec<T, D> mr = node[br];
+      node_rec<T, D> r;
+      T* b = box + uint64_t(i) * 2 * D;
+      if (!(ml.mass != T(0))) {  // left dead (src/bvh.h:225-228): copy left monopole
+        r    = ml;
+        r.bw = T(0);
+#pragma unroll
+        for (int k = 0; k < 2 * D; ++k) b[k] = T(0);
+      } else if (!(mr.mass != T(0))) {  // right dead (src/bvh.h:230-233): copy left node entirely
+        r = ml;
+#pragma unroll
+        for (int k = 0; k < 2 * D; ++k) b[k] = box[uint64_t(bl) * 2 * D + k];
+      } else {  // src/bvh.h:234-241
+        const T mass = ml.mass + mr.mass;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          r.p[k]   = (ml.mass * ml.p[k] + mr.mass * mr.p[k]) / mass;
+          b[k]     = fmin_(box[uint64_t(bl) * 2 * D + k], box[uint64_t(br) * 2 * D + k]);
+          b[D + k] = fmax_(box[uint64_t(bl) * 2 * D + D + k], box[uint64_t(br) * 2 * D + D + k]);
+        }
+        r.mass = mass;
+        r.bw   = node_width<T, D>(b);
+      }
+      node[i] = r;
+    }
+    if (l > l_lo) __syncthreads();  // single-block multi-level mode only
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9 traversal  (src/bvh.h:246-324)
+// One lane per body (bodies are Hilbert-sorted, so the 64 lanes of a wave walk nearly the same
+// path and their node records coalesce into a few L2 lines).  Bound: L2/HBM latency-bandwidth of the
+// node-record gather + FP64 VALU of the accepted terms.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void bvh_force_kernel(const node_rec<T, D>* __restrict__ node, const T* __restrict__ m,
+                                                       const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
+                                                       uint32_t first, uint32_t count, T theta2, uint32_t nlevels,
+                                                       uint32_t* __restrict__ counters) {
+  const uint32_t local = blockIdx.x * 64 + threadIdx.x;
+  if (local >= count) return;
+  const uint32_t i = first + local;
+  T xs[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xs[k]  = x[uint64_t(i) * D + k];
+    acc[k] = T(0);
+  }
+  uint32_t tree_index = 0, level = 0, covered = 0;
+  const uint32_t leaf_level = nlevels;
+  const uint32_t leaf_first = (1u << leaf_level) - 1u;
+  uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
+
+  while (covered < sz) {
+    if (level == leaf_level) {  // src/bvh.h:288-303
+      uint32_t bidx = tree_index - leaf_first;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (bidx < sz) {  // the self pair contributes exactly 0 (common.hpp), no `bidx != i` test needed
+          src_rec<T, D> s;
+#pragma unroll
+          for (int k = 0; k < D; ++k) s.p[k] = x[uint64_t(bidx) * D + k];
+          s.m = m[bidx];
+          pair_accumulate<T, D>(acc, xs, s);
+          if (COUNT && bidx != i) ++c_body;
+        }
+        ++bidx;
+      }
+      covered += 2;
+      if (COUNT) ++c_leaf;
+      // force_ascend_right: parent + 1 (src/bvh.h:272-275, :115-120)
+      tree_index = ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
+      level -= 1;
+    } else {
+      const node_rec<T, D> nd = node[tree_index];
+      if (COUNT) ++c_nodes;
+      bool approx;
+      {
+#pragma clang fp contract(off)
+        T d2 = T(0);  // dist2(xs, xj), src/vec.h:232-240: separate multiply and add
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          T di = xs[k] - nd.p[k];
+          d2   = d2 + di * di;
+        }
+        approx = nd.bw * nd.bw < theta2 * d2;  // can_approximate, src/bvh.h:246-248
+      }
+      if (approx) {
+        src_rec<T, D> s;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s.p[k] = nd.p[k];
+        s.m = nd.mass;
+        pair_accumulate<T, D>(acc, xs, s);
+        if (COUNT) ++c_mono;
+        covered += 1u << (nlevels - level);
+        if ((tree_index - 1u) & 1u) {  // right child -> parent + 1 (src/bvh.h:277-281)
+          tree_index = (level == 0) ? 1u : ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
+          level -= 1;
+        } else {
+          tree_index += 1;
+        }
+      } else {  // descend to the left child (src/bvh.h:126-130,283-286)
+        const uint32_t f = (1u << level) - 1u;
+        tree_index       = (tree_index - f) * 2u + f + (1u << level);
+        level += 1;
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+  if (COUNT) {
+    counters[uint64_t(i) * 4 + 0] = c_nodes;
+    counters[uint64_t(i) * 4 + 1] = c_leaf;
+    counters[uint64_t(i) * 4 + 2] = c_mono;
+    counters[uint64_t(i) * 4 + 3] = c_body;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static int check_tree(const nbody_bvh* t, const nbody_state* s, bool need_full) {
+  NB_ARG(t != nullptr, "nbody_bvh is NULL");
+  if (int r = check_state(s)) return r;
+  NB_ARG(t->dtype == s->dtype && t->dim == s->dim && t->n == s->sz, "bvh was created for (dtype=%d, dim=%d, n=%u), state is (%d, %d, %u)",
+         t->dtype, t->dim, t->n, s->dtype, s->dim, s->sz);
+  if (need_full) NB_ARG(s->first == 0 && s->count == s->sz, "this bvh phase needs the whole system (first=0, count=sz)");
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int bbox_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
+  hipLaunchKernelGGL((bbox_partial_kernel<T, D>), dim3(t->bbox_blocks), dim3(kB), 0, st, static_cast<const T*>(s->x), s->sz,
+                     static_cast<T*>(t->partials));
+  NB_HIP(hipGetLastError());
+  hipLaunchKernelGGL((bbox_final_kernel<T, D>), dim3(1), dim3(kB), 0, st, static_cast<const T*>(t->partials), t->bbox_blocks,
+                     static_cast<T*>(t->bbox));
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
+  const uint32_t n = s->sz;
+  hipLaunchKernelGGL((hilbert_keys_kernel<T, D>), dim3((n + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->x), n,
+                     static_cast<const T*>(t->bbox), t->keys[0]);
+  NB_HIP(hipGetLastError());
+  // keys[0] must survive for nbody_bvh_read(what=0): sort from a copy
+  NB_HIP(hipMemcpyAsync(t->keys[1], t->keys[0], sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, st));
+  // ping-pong between keys[1] and tmp-backed key buffer is avoided: use a third buffer carved from tmp
+  uint64_t* kbuf[2] = {t->keys[1], reinterpret_cast<uint64_t*>(t->tmp)};
+  const uint32_t nblk = t->sort_blocks;
+  const int key_bits  = (D == 2) ? 64 : 63;
+  int cur             = 0;
+  const uint32_t* idx_in = nullptr;
+  for (int shift = 0; shift < key_bits; shift += 8) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], n, shift, t->hist, nblk);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, t->hist, 256u * nblk);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], idx_in, kbuf[cur ^ 1], t->idx[cur ^ 1], n,
+                       shift, t->hist, nblk);
+    NB_HIP(hipGetLastError());
+    cur ^= 1;
+    idx_in = t->idx[cur];
+  }
+  t->final_buf = cur;
+  // permute the state in place: gather into tmp, copy back
+  T* tmp = static_cast<T*>(t->tmp);
+  hipLaunchKernelGGL((gather_kernel<T, D>), dim3((n + kB - 1) / kB), dim3(kB), 0, st, t->idx[cur], n, static_cast<const T*>(s->m),
+                     static_cast<const T*>(s->x), static_cast<const T*>(s->v), static_cast<const T*>(s->a),
+                     static_cast<const T*>(s->ao), tmp);
+  NB_HIP(hipGetLastError());
+  const size_t vb = sizeof(T) * size_t(n) * D;
+  NB_HIP(hipMemcpyAsync(s->x, tmp, vb, hipMemcpyDeviceToDevice, st));
+  NB_HIP(hipMemcpyAsync(s->v, tmp + size_t(n) * D, vb, hipMemcpyDeviceToDevice, st));
+  NB_HIP(hipMemcpyAsync(s->a, tmp + size_t(n) * D * 2, vb, hipMemcpyDeviceToDevice, st));
+  NB_HIP(hipMemcpyAsync(s->ao, tmp + size_t(n) * D * 3, vb, hipMemcpyDeviceToDevice, st));
+  NB_HIP(hipMemcpyAsync(s->m, tmp + size_t(n) * D * 4, sizeof(T) * size_t(n), hipMemcpyDeviceToDevice, st));
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
+  auto* node         = static_cast<node_rec<T, D>*>(t->node);
+  T* box             = static_cast<T*>(t->box);
+  const int last     = int(t->nlevels) - 1;
+  const uint32_t cnt = 1u << last;
+  hipLaunchKernelGGL((build_leaf_level_kernel<T, D>), dim3((cnt + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->m),
+                     static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, node, box);
+  NB_HIP(hipGetLastError());
+  int l = last - 1;
+  for (; l >= 0 && (1u << l) > uint32_t(kB); --l) {
+    hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3((1u << l) / kB), dim3(kB), 0, st, l, l, node, box);
+    NB_HIP(hipGetLastError());
+  }
+  if (l >= 0) {
+    hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3(1), dim3(kB), 0, st, l, 0, node, box);
+    NB_HIP(hipGetLastError());
+  }
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream_t st) {
+  if (s->count == 0) return NBODY_OK;
+  const T th  = static_cast<T>(theta);
+  const T th2 = th * th;  // src/bvh.h:252, in T
+  const uint32_t blocks = (s->count + 63) / 64;
+  auto* node = static_cast<const node_rec<T, D>*>(t->node);
+  if (t->counters_on)
+    hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), dim3(blocks), dim3(64), 0, st, node, static_cast<const T*>(s->m),
+                       static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, th2,
+                       t->nlevels, t->counters);
+  else
+    hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), dim3(blocks), dim3(64), 0, st, node, static_cast<const T*>(s->m),
+                       static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, th2,
+                       t->nlevels, t->counters);
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+}  // namespace nbody
+
+// ---- C ABI ------------------------------------------------------------------------------------------
+using namespace nbody;
+
+extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n) {
+  NB_ARG(out != nullptr, "out is NULL");
+  *out = nullptr;
+  NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
+  NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
+  NB_ARG(n >= 2 && n <= (1u << 30), "bvh needs 2 <= n <= 2^30 (got %u)", n);
+  auto* t  = new nbody_bvh;
+  t->dtype = dtype;
+  t->dim   = dim;
+  t->n     = n;
+  t->tsz   = dtype == NBODY_F32 ? 4 : 8;
+  uint32_t nleafs = 1, nl = 0;  // bit_ceil / countr_zero (src/bvh.h:151-157)
+  while (nleafs < n) {
+    nleafs <<= 1;
+    ++nl;
+  }
+  t->nlevels     = nl;
+  t->nnodes      = (1u << nl) - 1u;
+  t->sort_blocks = (n + kSortTile - 1) / kSortTile;
+  t->bbox_blocks = (n + kB * 8 - 1) / (kB * 8);
+  if (t->bbox_blocks > 1024) t->bbox_blocks = 1024;
+  const size_t D = size_t(dim);
+  size_t rb      = (D + 2) * t->tsz;
+  t->rec_bytes   = rb <= 16 ? 16 : (rb <= 32 ? 32 : 64);
+  // tmp doubles as a radix key buffer (u64[n]) and as the gather scratch (T[n*(4D+1)])
+  size_t tmp_bytes = t->tsz * size_t(n) * (4 * D + 1);
+  if (tmp_bytes < sizeof(uint64_t) * size_t(n)) tmp_bytes = sizeof(uint64_t) * size_t(n);
+  auto fail = [&](hipError_t e, const char* what) {
+    int r = hip_fail(e, what, __FILE__, __LINE__);
+    nbody_bvh_destroy(t);
+    return r;
+  };
+#define NB_ALLOC(ptr, bytes)                                         \
+  do {                                                               \
+    hipError_t e_ = hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes)); \
+    if (e_ != hipSuccess) return fail(e_, "hipMalloc(" #ptr ")");    \
+  } while (0)
+  NB_ALLOC(t->bbox, t->tsz * 3 * D);
+  NB_ALLOC(t->partials, t->tsz * 2 * D * t->bbox_blocks);
+  NB_ALLOC(t->keys[0], sizeof(uint64_t) * size_t(n));
+  NB_ALLOC(t->keys[1], sizeof(uint64_t) * size_t(n));
+  NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
+  NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
+  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * size_t(t->sort_blocks));
+  NB_ALLOC(t->tmp, tmp_bytes);
+  NB_ALLOC(t->node, t->rec_bytes * size_t(t->nnodes));
+  NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
+#undef NB_ALLOC
+  *out = t;
+  return NBODY_OK;
+}
+
+extern "C" void nbody_bvh_destroy(nbody_bvh* t) {
+  if (!t) return;
+  (void)hipFree(t->bbox);
+  (void)hipFree(t->partials);
+  (void)hipFree(t->keys[0]);
+  (void)hipFree(t->keys[1]);
+  (void)hipFree(t->idx[0]);
+  (void)hipFree(t->idx[1]);
+  (void)hipFree(t->hist);
+  (void)hipFree(t->tmp);
+  (void)hipFree(t->node);
+  (void)hipFree(t->box);
+  (void)hipFree(t->counters);
+  delete t;
+}
+
+extern "C" uint32_t nbody_bvh_nnodes(const nbody_bvh* t) { return t ? t->nnodes : 0; }
+
+extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
+  NB_ARG(t != nullptr, "nbody_bvh is NULL");
+  if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 4 * size_t(t->n)));
+  t->counters_on = on != 0;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* stream) {
+  if (int r = check_tree(t, s, false)) return r;
+  int r = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return bbox_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->have_bbox = true;
+  return r;
+}
+
+extern "C" int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xmax_out, void* stream) {
+  NB_ARG(t != nullptr && xmin_out && xmax_out, "NULL argument");
+  if (!t->have_bbox) {
+    set_error("nbody_bvh_get_bounding_box before nbody_bvh_bounding_box");
+    return NBODY_ERR_STATE;
+  }
+  char buf[2 * 3 * 8];
+  NB_HIP(hipMemcpyAsync(buf, t->bbox, t->tsz * 2 * t->dim, hipMemcpyDeviceToHost, as_stream(stream)));
+  NB_HIP(hipStreamSynchronize(as_stream(stream)));
+  memcpy(xmin_out, buf, t->tsz * t->dim);
+  memcpy(xmax_out, buf + t->tsz * t->dim, t->tsz * t->dim);
+  return NBODY_OK;
+}
+
+extern "C" int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* stream) {
+  if (int r = check_tree(t, s, true)) return r;
+  if (!t->have_bbox) {
+    set_error("nbody_bvh_hilbert_sort before nbody_bvh_bounding_box");
+    return NBODY_ERR_STATE;
+  }
+  int r = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return sort_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->sorted = true;
+  return r;
+}
+
+extern "C" int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* stream) {
+  if (int r = check_tree(t, s, false)) return r;
+  int r = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return build_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->built = true;
+  return r;
+}
+
+extern "C" int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, double theta, void* stream) {
+  if (int r = check_tree(t, s, false)) return r;
+  if (!t->built) {
+    set_error("nbody_bvh_compute_force before nbody_bvh_build_tree");
+    return NBODY_ERR_STATE;
+  }
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return force_run<typename TG::type, TG::dim>(t, s, theta, as_stream(stream));
+  });
+}
+
+extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream) {
+  NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
+  const size_t D = size_t(t->dim);
+  hipStream_t st = as_stream(stream);
+  auto copy_out = [&](const void* dev, size_t need) -> int {
+    NB_ARG(bytes == need, "nbody_bvh_read(what=%d): expected %zu bytes, got %zu", what, need, bytes);
+    NB_HIP(hipMemcpyAsync(host_out, dev, need, hipMemcpyDeviceToHost, st));
+    NB_HIP(hipStreamSynchronize(st));
+    return NBODY_OK;
+  };
+  switch (what) {
+    case 0: return copy_out(t->keys[0], sizeof(uint64_t) * size_t(t->n));
+    case 1: return copy_out(t->idx[t->final_buf], sizeof(uint32_t) * size_t(t->n));
+    case 3:
+    case 2: {
+      // unpack node records -> T[nnodes][D+1] (what=2) or T[nnodes] (what=3)
+      const size_t need = what == 2 ? t->tsz * (D + 1) * t->nnodes : t->tsz * t->nnodes;
+      NB_ARG(bytes == need, "nbody_bvh_read(what=%d): expected %zu bytes, got %zu", what, need, bytes);
+      char* raw = static_cast<char*>(malloc(t->rec_bytes * size_t(t->nnodes)));
+      NB_ARG(raw != nullptr, "out of host memory");
+      hipError_t e = hipMemcpyAsync(raw, t->node, t->rec_bytes * size_t(t->nnodes), hipMemcpyDeviceToHost, st);
+      if (e == hipSuccess) e = hipStreamSynchronize(st);
+      if (e != hipSuccess) {
+        free(raw);
+        return hip_fail(e, "read node records", __FILE__, __LINE__);
+      }
+      char* o = static_cast<char*>(host_out);
+      for (size_t i = 0; i < t->nnodes; ++i) {
+        const char* r = raw + i * t->rec_bytes;
+        if (what == 2) memcpy(o + i * t->tsz * (D + 1), r, t->tsz * (D + 1));
+        else memcpy(o + i * t->tsz, r + t->tsz * (D + 1), t->tsz);
+      }
+      free(raw);
+      return NBODY_OK;
+    }
+    case 4: return copy_out(t->box, t->tsz * 2 * D * size_t(t->nnodes));
+    case 5:
+      NB_ARG(t->counters != nullptr, "counters were never enabled");
+      return copy_out(t->counters, sizeof(uint32_t) * 4 * size_t(t->n));
+    default: set_error("nbody_bvh_read: unknown what=%d", what); return NBODY_ERR_ARG;
+  }
+}

@@ -1,0 +1,138 @@
+// Shared helpers for the gfx950 N-body backend: error plumbing, (dtype, dim) dispatch and the pair
+// kernel math.  Device code here is written for CDNA4 only (wave64, no portability layer).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "../../include/nbody_hip.h"
+
+namespace nbody {
+
+// ---- error plumbing -----------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what, const char* file, int line);
+
+#define NB_HIP(call)                                                                   \
+  do {                                                                                 \
+    hipError_t e_ = (call);                                                            \
+    if (e_ != hipSuccess) return ::nbody::hip_fail(e_, #call, __FILE__, __LINE__);     \
+  } while (0)
+
+#define NB_ARG(cond, ...)                \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::nbody::set_error(__VA_ARGS__);   \
+      return NBODY_ERR_ARG;              \
+    }                                    \
+  } while (0)
+
+inline int check_state(const nbody_state* s) {
+  NB_ARG(s != nullptr, "nbody_state is NULL");
+  NB_ARG(s->dtype == NBODY_F32 || s->dtype == NBODY_F64, "bad dtype %d", s->dtype);
+  NB_ARG(s->dim == 2 || s->dim == 3, "bad dim %d (must be 2 or 3)", s->dim);
+  NB_ARG(s->m && s->x && s->v && s->a && s->ao, "nbody_state has a NULL array pointer");
+  NB_ARG(uint64_t(s->first) + uint64_t(s->count) <= uint64_t(s->sz), "shard [%u, %u+%u) exceeds sz=%u", s->first, s->first,
+         s->count, s->sz);
+  return NBODY_OK;
+}
+
+// Runtime (dtype, dim) -> compile-time <T, D>.  F is a generic lambda taking (T tag, integral_constant D).
+template <typename T, int D>
+struct tag {
+  using type = T;
+  static constexpr int dim = D;
+};
+
+template <typename F>
+inline int dispatch(int dtype, int dim, F&& f) {
+  if (dtype == NBODY_F32 && dim == 2) return f(tag<float, 2>{});
+  if (dtype == NBODY_F32 && dim == 3) return f(tag<float, 3>{});
+  if (dtype == NBODY_F64 && dim == 2) return f(tag<double, 2>{});
+  if (dtype == NBODY_F64 && dim == 3) return f(tag<double, 3>{});
+  set_error("unsupported (dtype=%d, dim=%d)", dtype, dim);
+  return NBODY_ERR_ARG;
+}
+
+// ---- pair math -----------------------------------------------------------------------------------
+// The reference pair term (src/all_pairs.h:23, src/bvh.h:297,308; dist3 at src/vec.h:249-252) is
+//     m_j * (x_j - x_i) / (pow(r2, 3/2) + eps)
+// i.e. one pow, one add and D divisions per pair.  On gfx950 FP64 transcendentals run at quarter
+// rate and do not overlap the FMA pipe (profiles/r01_valu_rates_microbench.txt), and an IEEE divide is
+// a ~10-instruction sequence, so the kernel evaluates   w = m_j / (r2*sqrt(r2) + eps)   once per pair
+// with two 2^-24 hardware seeds (v_rsq, v_rcp) each polished by one third-order step, then D FMAs.
+// Error budget vs the exact expression: < 2 ulp per term (tests/test_pair_math.py pins it).
+//
+// r2 must be > 0: callers fold TINY into the first FMA of r2 (r2 = fma(dx,dx,TINY)), which makes the
+// self term and coincident bodies evaluate to exactly 0 * (finite) = 0 — the value the reference
+// gets from `(m*0)/eps` (self term skipped by `if (i == j) continue`) — with no branch
+// and no select (a v_cmp + 2 v_cndmask select costs ~5 FMA slots on this chip).
+template <typename T>
+struct pair_math;
+
+template <>
+struct pair_math<double> {
+  static constexpr double tiny = 1e-300;
+  // returns mj / (r2 * sqrt(r2) + DBL_EPSILON)
+  __device__ static __forceinline__ double weight(double r2, double mj) {
+    double y0 = __builtin_amdgcn_rsq(r2);     // ~2^-24 relative
+    double h  = r2 * y0;                      // ~sqrt(r2)
+    double e  = __builtin_fma(-h, y0, 1.0);   // 1 - r2*y0^2
+    double p  = __builtin_fma(e, 0.375, 0.5);
+    double g  = h * e;
+    double s  = __builtin_fma(g, p, h);       // sqrt(r2)*(1 + O(e^3))
+    double d3 = __builtin_fma(r2, s, DBL_EPSILON);
+    double z0 = __builtin_amdgcn_rcp(d3);     // ~2^-24 relative
+    double e2 = __builtin_fma(-d3, z0, 1.0);
+    double q  = __builtin_fma(e2, e2, e2);    // e2 + e2^2
+    double zm = z0 * mj;
+    return __builtin_fma(zm, q, zm);          // mj/d3 * (1 + O(e2^3))
+  }
+};
+
+template <>
+struct pair_math<float> {
+  static constexpr float tiny = 1e-37f;
+  // returns mj / (r2 * sqrt(r2) + FLT_EPSILON); v_rsq_f32 / v_rcp_f32 are 1 ulp, one Newton step each
+  // keeps the term within ~1.5 ulp of the exact expression (the reference's own powf/divide chain
+  // is not reproducible across its builds at this level).
+  __device__ static __forceinline__ float weight(float r2, float mj) {
+    float y0 = __builtin_amdgcn_rsqf(r2);
+    float h  = r2 * y0;
+    float e  = __builtin_fmaf(-h, y0, 1.0f);
+    float s  = __builtin_fmaf(h * 0.5f, e, h);
+    float d3 = __builtin_fmaf(r2, s, FLT_EPSILON);
+    float z0 = __builtin_amdgcn_rcpf(d3);
+    float e2 = __builtin_fmaf(-d3, z0, 1.0f);
+    float zm = z0 * mj;
+    return __builtin_fmaf(zm, e2, zm);
+  }
+};
+
+// LDS source record: (x[0..D-1], m) padded to a power-of-two size so one or two ds_read_b128 fetch it.
+template <typename T, int D>
+struct alignas(sizeof(T) * 4) src_rec {
+  T p[3];  // D used
+  T m;
+};
+
+// acc += w * (xj - xi) with r2 built by FMAs starting from TINY.
+template <typename T, int D>
+__device__ __forceinline__ void pair_accumulate(T (&acc)[D], const T (&xi)[D], const src_rec<T, D>& s) {
+  T d[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) d[k] = s.p[k] - xi[k];
+  T r2 = pair_math<T>::tiny;
+#pragma unroll
+  for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+  T w = pair_math<T>::weight(r2, s.m);
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+}  // namespace nbody

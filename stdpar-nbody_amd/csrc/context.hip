@@ -1,0 +1,147 @@
+// Error plumbing, device identification and the owning context (device mirrors of a host System)
+// used by the ISO-C++ CLI host.  See include/nbody_hip.h for the contract.
+#include "common.hpp"
+
+#include <cstring>
+#include <string>
+
+namespace nbody {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int hip_fail(hipError_t e, const char* what, const char* file, int line) {
+  set_error("HIP error %d (%s) in %s at %s:%d", int(e), hipGetErrorString(e), what, file, line);
+  return NBODY_ERR_HIP;
+}
+
+}  // namespace nbody
+
+using namespace nbody;
+
+struct nbody_ctx {
+  int dtype = 0, dim = 0, device = 0;
+  uint32_t n = 0;
+  size_t tsz = 0;
+  void *m = nullptr, *x = nullptr, *v = nullptr, *a = nullptr, *ao = nullptr;
+  double dt = 0, c = 0;
+  hipStream_t stream = nullptr;
+};
+
+extern "C" const char* nbody_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int nbody_device_info(int device, char* arch_out, size_t arch_len, int* cu_count) {
+  int ndev = 0;
+  NB_HIP(hipGetDeviceCount(&ndev));
+  NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
+  hipDeviceProp_t p;
+  NB_HIP(hipGetDeviceProperties(&p, device));
+  if (arch_out && arch_len) {
+    strncpy(arch_out, p.gcnArchName, arch_len - 1);
+    arch_out[arch_len - 1] = 0;
+  }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int device) {
+  NB_ARG(out != nullptr, "out is NULL");
+  *out = nullptr;
+  NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
+  NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
+  NB_ARG(n >= 1, "n must be >= 1");
+  int ndev = 0;
+  NB_HIP(hipGetDeviceCount(&ndev));
+  NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
+  NB_HIP(hipSetDevice(device));
+  auto* c   = new nbody_ctx;
+  c->dtype  = dtype;
+  c->dim    = dim;
+  c->n      = n;
+  c->device = device;
+  c->tsz    = dtype == NBODY_F32 ? 4 : 8;
+  const size_t vb = c->tsz * size_t(n) * size_t(dim);
+  hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipMalloc(&c->m, c->tsz * size_t(n));
+  if (e == hipSuccess) e = hipMalloc(&c->x, vb);
+  if (e == hipSuccess) e = hipMalloc(&c->v, vb);
+  if (e == hipSuccess) e = hipMalloc(&c->a, vb);
+  if (e == hipSuccess) e = hipMalloc(&c->ao, vb);
+  if (e != hipSuccess) {
+    int r = hip_fail(e, "nbody_create allocation", __FILE__, __LINE__);
+    nbody_destroy(c);
+    return r;
+  }
+  *out = c;
+  return NBODY_OK;
+}
+
+extern "C" void nbody_destroy(nbody_ctx* c) {
+  if (!c) return;
+  (void)hipFree(c->m);
+  (void)hipFree(c->x);
+  (void)hipFree(c->v);
+  (void)hipFree(c->a);
+  (void)hipFree(c->ao);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+extern "C" int nbody_upload(nbody_ctx* c, const void* m, const void* x, const void* v, const void* a, const void* ao, double dt,
+                            double cc) {
+  NB_ARG(c && m && x && v && a && ao, "NULL argument");
+  const size_t vb = c->tsz * size_t(c->n) * size_t(c->dim);
+  NB_HIP(hipMemcpyAsync(c->m, m, c->tsz * size_t(c->n), hipMemcpyHostToDevice, c->stream));
+  NB_HIP(hipMemcpyAsync(c->x, x, vb, hipMemcpyHostToDevice, c->stream));
+  NB_HIP(hipMemcpyAsync(c->v, v, vb, hipMemcpyHostToDevice, c->stream));
+  NB_HIP(hipMemcpyAsync(c->a, a, vb, hipMemcpyHostToDevice, c->stream));
+  NB_HIP(hipMemcpyAsync(c->ao, ao, vb, hipMemcpyHostToDevice, c->stream));
+  NB_HIP(hipStreamSynchronize(c->stream));
+  c->dt = dt;
+  c->c  = cc;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_download(nbody_ctx* c, void* m, void* x, void* v, void* a, void* ao) {
+  NB_ARG(c != nullptr, "ctx is NULL");
+  const size_t vb = c->tsz * size_t(c->n) * size_t(c->dim);
+  if (m) NB_HIP(hipMemcpyAsync(m, c->m, c->tsz * size_t(c->n), hipMemcpyDeviceToHost, c->stream));
+  if (x) NB_HIP(hipMemcpyAsync(x, c->x, vb, hipMemcpyDeviceToHost, c->stream));
+  if (v) NB_HIP(hipMemcpyAsync(v, c->v, vb, hipMemcpyDeviceToHost, c->stream));
+  if (a) NB_HIP(hipMemcpyAsync(a, c->a, vb, hipMemcpyDeviceToHost, c->stream));
+  if (ao) NB_HIP(hipMemcpyAsync(ao, c->ao, vb, hipMemcpyDeviceToHost, c->stream));
+  NB_HIP(hipStreamSynchronize(c->stream));
+  return NBODY_OK;
+}
+
+extern "C" int nbody_ctx_state(nbody_ctx* c, nbody_state* out) {
+  NB_ARG(c && out, "NULL argument");
+  out->m     = c->m;
+  out->x     = c->x;
+  out->v     = c->v;
+  out->a     = c->a;
+  out->ao    = c->ao;
+  out->dt    = c->dt;
+  out->c     = c->c;
+  out->sz    = c->n;
+  out->first = 0;
+  out->count = c->n;
+  out->dtype = c->dtype;
+  out->dim   = c->dim;
+  return NBODY_OK;
+}
+
+extern "C" void* nbody_ctx_stream(nbody_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
+
+extern "C" int nbody_stream_sync(void* stream) {
+  NB_HIP(hipStreamSynchronize(as_stream(stream)));
+  return NBODY_OK;
+}

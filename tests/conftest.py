@@ -1,0 +1,63 @@
+"""pytest configuration: `gpu` marker, package loader (the package directory has a hyphen), fixtures."""
+import importlib.util
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def load_package():
+    """Import stdpar-nbody_amd/ under the module name stdpar_nbody_amd."""
+    if "stdpar_nbody_amd" in sys.modules:
+        return sys.modules["stdpar_nbody_amd"]
+    path = os.path.join(ROOT, "stdpar-nbody_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("stdpar_nbody_amd", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["stdpar_nbody_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def nb():
+    return load_package()
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as O
+    O.lib()  # builds liboracle.so on first use if missing
+    return O
+
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="session")
+def golden_positions():
+    meta = json.load(open(os.path.join(GOLDEN, "positions_meta.json")))
+    data = np.load(os.path.join(GOLDEN, "positions.npz"))
+    return meta, data
+
+
+@pytest.fixture(scope="session")
+def golden_print_state():
+    return json.load(open(os.path.join(GOLDEN, "print_state.json")))
+
+
+@pytest.fixture(scope="session")
+def golden_hilbert():
+    return json.load(open(os.path.join(GOLDEN, "hilbert.json")))
+
+
+DT = {"float": 0, "double": 1}

@@ -1,0 +1,68 @@
+"""CPU: the C-ABI library loads (no GPU needed to dlopen it) and exports exactly what include/nbody_hip.h declares."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+
+def _header_symbols():
+    text = open(os.path.join(ROOT, "include", "nbody_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nbody_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_and_binding_list_agree(nb):
+    assert _header_symbols() == sorted(nb.ABI_SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol(nb):
+    if not os.path.exists(nb.LIB_PATH):
+        nb.build()
+    L = ctypes.CDLL(nb.LIB_PATH)
+    for sym in _header_symbols():
+        assert hasattr(L, sym), f"libnbody_hip.so does not export {sym}"
+
+
+def test_code_object_is_gfx950_only(nb):
+    """Write for MI355X only: the embedded code objects target gfx950 and no other GPU arch."""
+    raw = open(nb.LIB_PATH, "rb").read()
+    archs = set(re.findall(rb"amdgcn-amd-amdhsa--(gfx[0-9a-z]+)", raw))
+    assert archs == {b"gfx950"}, archs
+
+
+def test_argument_errors_do_not_need_a_gpu(nb):
+    """Bad arguments are rejected before any HIP call, with a message (no exceptions cross the C boundary)."""
+    L = nb.lib()
+    st = nb.nbody_state()
+    st.dtype, st.dim = 7, 3
+    assert L.nbody_all_pairs_force(ctypes.byref(st), None) == 1
+    assert b"dtype" in L.nbody_last_error()
+    st.dtype, st.dim = nb.F64, 4
+    assert L.nbody_accelerate_step(ctypes.byref(st), None) == 1
+    assert b"dim" in L.nbody_last_error()
+    assert L.nbody_all_pairs_configure(3, 0) == 1
+    assert L.nbody_all_pairs_force(None, None) == 1
+
+
+def test_no_cpu_fallback_in_product(nb):
+    """The product must not reference the oracle, and must fail loudly when the extension is missing."""
+    pkg = os.path.join(ROOT, "stdpar-nbody_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in src and "import oracle" not in src and "from oracle" not in src, f
+    saved = nb.LIB_PATH
+    try:
+        nb.LIB_PATH = saved + ".missing"
+        import importlib
+        nb._lib = None
+        with pytest.raises(nb.NbodyError):
+            nb.lib()
+    finally:
+        nb.LIB_PATH = saved
+        nb._lib = None

@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Headline benchmark: body-steps/s (+ % of gfx950 FP64 vector peak) for 3D double all-pairs on the
+synthetic galaxy init, N = 2^20 bodies, on 1/2/4/8 MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One process per GPU.  A "step" is one pass of the hot path over all bodies: K1 all-pairs force on the
+rank's shard of targets (all N sources), K3 leapfrog on the shard, then one RCCL all-gather of the
+updated positions over xGMI (torch.distributed, backend "nccl").  Total work is fixed as N grows
+(strong scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+PyTorch is plumbing here (device memory, streams, the process group); all arithmetic is in
+stdpar-nbody_amd/libnbody_hip.so through its C ABI.  The CPU baseline leg times the oracle's
+restatement of the reference loop on this box's host cores (reported, not the target).
+"""
+import argparse
+import ctypes as C
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FLOP_PER_INTERACTION = 20        # D=3: 3 sub + 5 r2 + 2 (sqrt, *r2) + 1 (+eps) + 3 (m*d) + 3 (/) + 3 (acc)
+
+
+def load_package():
+    path = os.path.join(ROOT, "stdpar-nbody_amd", "__init__.py")
+    spec = importlib.util.spec_from_file_location("stdpar_nbody_amd", path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules["stdpar_nbody_amd"] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def cpu_baseline(n, hs, target_seconds=15.0):
+    """Time the oracle's all-pairs loop (reference algorithm, src/all_pairs.h:14-27) on the host cores for a
+    bounded sample of target bodies against all n sources.  Built with the reference's own CPU flags
+    (-Ofast -march=native, ci/run:112-113) and parallelised over targets with OpenMP on every core."""
+    import numpy as np
+    src = os.path.join(ROOT, "oracle", "nbody_oracle.c")
+    tmp = tempfile.mkdtemp(prefix="nbody_cpu_")
+    so = os.path.join(tmp, "liboracle_fast.so")
+    flags = ["-std=c11", "-Ofast", "-march=native", "-fopenmp", "-fPIC", "-shared", "-Wno-unused-function"]
+    try:
+        subprocess.check_call(["gcc"] + flags + [src, "-o", so, "-lm"], stderr=subprocess.DEVNULL)
+        build = "gcc -Ofast -march=native -fopenmp"
+    except Exception:
+        sys.path.insert(0, ROOT)
+        import oracle as O
+        O.lib()
+        so, build = O.LIB_PATH, "gcc -O2 -fopenmp"
+    L = C.CDLL(so)
+    cores = len(os.sched_getaffinity(0))
+    a = np.zeros((n, 3), np.float64)
+
+    def run(count):
+        t0 = time.perf_counter()
+        rc = L.oracle_all_pairs_force(1, 3, hs.m.ctypes.data_as(C.c_void_p), hs.x.ctypes.data_as(C.c_void_p),
+                                      a.ctypes.data_as(C.c_void_p), C.c_double(hs.c), C.c_uint32(n), C.c_uint32(0), C.c_uint32(count))
+        assert rc == 0
+        return time.perf_counter() - t0
+
+    probe = min(n, 64 * cores)
+    t = run(probe)
+    count = int(min(n, max(probe, probe * target_seconds / max(t, 1e-6))))
+    count = max(cores, count // cores * cores)
+    t = run(count)
+    return {"value": count / t, "unit": "body-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{count} of {n} target bodies x all {n} sources, one force pass, {t:.1f} s, {build}",
+            "interactions_per_s": count * (n - 1) / t}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default 2^20, the BASELINE.json metric config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    nb = load_package()
+    par = nb.parallel
+
+    # synthetic galaxy init with the product's host generator (host/models.hpp == src/models.h:112-136)
+    hs = nb.build_model(nb.F64, 3, "galaxy", args.n)
+    n = hs.n
+    sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev)
+
+    def step():
+        sim.step()
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    force_events = []
+    for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sim.step(force_events=(e0, e1))
+        force_events.append((e0, e1))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel: K1.  Algorithmic flops per launch = 20 x (targets of this rank) x (n - 1)
+    k1_ms = sum(a.elapsed_time(b) for a, b in force_events) / max(1, len(force_events))
+    flops_per_launch = FLOP_PER_INTERACTION * sim.count * (n - 1)
+    achieved = flops_per_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
+
+    if rank == 0:
+        value = n * args.steps / elapsed
+        whole_job_tflops = FLOP_PER_INTERACTION * n * (n - 1) * args.steps / elapsed / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
+        if os.path.exists(pmc):
+            rec = json.load(open(pmc))
+            if rec.get("n") == n and rec.get("gpus") == world:
+                traffic = rec.get("bytes_per_launch")
+        out = {
+            "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
+            "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "all-pairs 3D double, galaxy init (mt19937 seed 42), n=%d" % n, "n_bodies": n,
+                       "parallelism": "bodies sharded over %d GPU(s), RCCL all-gather(x) per step" % world if world > 1
+                       else "single GPU", "split": sim.describe()},
+            "pct_fp64_peak": 100.0 * whole_job_tflops / (FP64_VECTOR_PEAK_TFLOPS * world),
+            "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_kernel<double,3>", "achieved": achieved,
+                         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                         "traffic": traffic, "avg_launch_ms": k1_ms,
+                         "note": "north_star forbids MFMA for this path; bound is the FP64 vector pipe "
+                                 "(20 algorithmic flop per ordered pair, SURVEY 8d)"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(n, hs)
+            except Exception as ex:  # the baseline is a reported extra; never lose the GPU line over it
+                out["cpu_baseline"] = {"value": None, "unit": "body-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

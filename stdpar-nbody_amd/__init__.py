@@ -271,6 +271,22 @@ class DeviceSystem:
         b.compute_force(st, theta, self.stream)
 
 
+def _load_sharded():
+    import importlib.util
+    import sys
+    name = __name__ + ".sharded"
+    if name in sys.modules:
+        return sys.modules[name]
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, "sharded.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+parallel = _load_sharded()
+
+
 def executed_steps(steps, csv_detailed, warmup=10):
     """Step-count semantics of the reference drivers."""
     return steps if csv_detailed else max(steps, warmup)

@@ -1,0 +1,124 @@
+"""Body sharding for multi-GPU all-pairs: one process per GPU, targets split contiguously by rank, every
+rank keeps all N positions/masses, and ONE exchange per step — an all-gather of the updated position
+shards (RCCL over xGMI through torch.distributed; north_star / SURVEY §8e).  Nothing else moves:
+v, a, ao stay local; masses are constant and replicated at start-up.
+
+The reference has no counterpart (single process, single device).  bvh and all-pairs-collapsed do not
+shard ("replicas only").  The per-target summation order does not depend on the shard window, so any
+world size gives bitwise the same trajectory as one GPU (tests/test_gpu_all_pairs.py checks this with
+shard windows on one GPU; tests/test_sharded_gloo.py checks the exchange logic with world_size 2).
+
+torch is used for device memory, the stream handle and the process group only.
+"""
+import ctypes as C
+
+import numpy as np
+
+
+def shard_range(n, rank, world):
+    """Contiguous balanced split: rank r owns [n*r//world, n*(r+1)//world)."""
+    return (n * rank) // world, (n * (rank + 1)) // world
+
+
+class HipOps:
+    """Phase calls through the C ABI on raw device pointers (include/nbody_hip.h)."""
+
+    def __init__(self, pkg):
+        self.pkg = pkg
+        self.lib = pkg.lib()
+
+    def all_pairs_force(self, st, stream):
+        rc = self.lib.nbody_all_pairs_force(C.byref(st), C.c_void_p(stream))
+        if rc:
+            raise self.pkg.NbodyError(self.lib.nbody_last_error().decode())
+
+    def accelerate_step(self, st, stream):
+        rc = self.lib.nbody_accelerate_step(C.byref(st), C.c_void_p(stream))
+        if rc:
+            raise self.pkg.NbodyError(self.lib.nbody_last_error().decode())
+
+
+class ShardedAllPairs:
+    """run_all_pairs' step (force, then accelerate_step; src/all_pairs.h:86-91) over a shard of targets."""
+
+    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = rank, world
+        self.n, self.dim, self.dtype = hs.n, hs.dim, hs.dtype
+        self.first, end = shard_range(hs.n, rank, world)
+        self.count = end - self.first
+        self.device = torch_device if torch_device is not None else torch.device("cpu")
+        if ops is None:
+            import sys
+            pkg = pkg or sys.modules["stdpar_nbody_amd"]
+            ops = HipOps(pkg)
+            self._state_cls = pkg.nbody_state
+        else:
+            self._state_cls = None
+        self.ops = ops
+        to = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+        self.m = to(hs.m)                       # all bodies
+        self.x = to(hs.x)                       # all bodies; rows [first, first+count) are ours to update
+        self.v = to(hs.v[self.first:end])       # owned bodies only
+        self.a = to(hs.a[self.first:end])
+        self.ao = to(hs.ao[self.first:end])
+        self.dt, self.c = float(hs.dt), float(hs.c)
+        self.equal = hs.n % world == 0
+        self.send = torch.empty_like(self.x[self.first:end]) if world > 1 and self.equal else None
+
+    def state(self):
+        if self._state_cls is None:  # test ops work on the tensors directly
+            return self
+        st = self._state_cls()
+        st.m, st.x = self.m.data_ptr(), self.x.data_ptr()
+        st.v, st.a, st.ao = self.v.data_ptr(), self.a.data_ptr(), self.ao.data_ptr()
+        st.dt, st.c = self.dt, self.c
+        st.sz, st.first, st.count = self.n, self.first, self.count
+        st.dtype, st.dim = self.dtype, self.dim
+        return st
+
+    def _stream(self):
+        if self.device.type == "cuda":
+            return self.torch.cuda.current_stream(self.device).cuda_stream
+        return None
+
+    def exchange_positions(self):
+        """The one collective of the path: all ranks end up with every rank's updated position shard."""
+        if self.world == 1:
+            return
+        end = self.first + self.count
+        if self.equal:
+            self.send.copy_(self.x[self.first:end])
+            self.dist.all_gather_into_tensor(self.x, self.send)
+        else:  # uneven shards: one broadcast per owner
+            for r in range(self.world):
+                f, e = shard_range(self.n, r, self.world)
+                self.dist.broadcast(self.x[f:e], src=r)
+
+    def step(self, force_events=None):
+        st, stream = self.state(), self._stream()
+        if force_events:
+            force_events[0].record()
+        self.ops.all_pairs_force(st, stream)
+        if force_events:
+            force_events[1].record()
+        self.ops.accelerate_step(st, stream)
+        self.exchange_positions()
+
+    def gather_state(self):
+        """Full (x, v, a) on every rank as numpy, for checks: v and a are gathered too (test/diagnostic only)."""
+        torch, dist = self.torch, self.dist
+        x = self.x.cpu().numpy().copy()
+        if self.world == 1:
+            return x, self.v.cpu().numpy().copy(), self.a.cpu().numpy().copy()
+        outs = []
+        for t in (self.v, self.a):
+            parts = [None] * self.world
+            dist.all_gather_object(parts, t.cpu().numpy())
+            outs.append(np.concatenate(parts, axis=0))
+        return x, outs[0], outs[1]
+
+    def describe(self):
+        return f"rank shard {self.count} of {self.n} targets, all-gather {'into_tensor' if self.equal else 'per-owner broadcast'}"

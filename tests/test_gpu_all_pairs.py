@@ -1,0 +1,250 @@
+"""GPU parity: K1 all-pairs, K2 all-pairs-collapsed, K3 leapfrog through the C ABI vs the oracle and the
+reference-generated fixtures.
+
+Tolerances (stated once, used everywhere below):
+  * integer / copy / K3 leapfrog: bit-exact.
+  * double forces: |a_gpu - a_ref| <= 1e-12 * max|a_ref|  (the kernel's pair term is < 2 ulp; the rest is
+    summation order: the reference sums j ascending in one chain, the kernel in 4 wave-partials).
+    Two legitimate builds of the reference (-O2 vs -Ofast) differ by 3.6e-15 after one step.
+  * double trajectories vs reference frames: rel 1e-11 of the position scale after <= 20 steps.
+  * float forces: 2e-5 * max|a_ref|; float trajectories: 2e-3 relative (the reference itself is not
+    reproducible across its own builds in float).
+"""
+import numpy as np
+import pytest
+
+from conftest import DT
+
+pytestmark = pytest.mark.gpu
+
+FORCE_TOL = {0: 2e-5, 1: 1e-12}
+TRAJ_TOL = {0: 2e-3, 1: 1e-11}
+
+
+def maxrel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_all_pairs_force_vs_oracle(nb, oracle, dtype, dim):
+    for wl, n in (("uniform", 1), ("uniform", 2), ("uniform", 63), ("uniform", 64), ("uniform", 65), ("galaxy", 511),
+                  ("uniform", 512), ("galaxy", 513), ("uniform", 1025), ("galaxy", 4099)):
+        ref = oracle.build_model(dtype, dim, wl, n)
+        hs = nb.build_model(dtype, dim, wl, n)
+        dev = nb.DeviceSystem.from_host(hs)
+        oracle.all_pairs_force(ref)
+        for split, tpt in ((0, 0), (1, 1), (1, 2), (2, 1), (2, 2), (4, 1), (4, 2)):
+            nb.configure_all_pairs(split, tpt)
+            dev.all_pairs_force()
+            out = dev.download()
+            assert maxrel(out.a, ref.a) <= FORCE_TOL[dtype], (wl, n, split, tpt)
+        nb.configure_all_pairs(0, 0)
+        dev.close()
+
+
+def test_pair_term_accuracy_in_ulps(nb, oracle):
+    """split=1 sums in the reference's order, so what is left is the pair math: <= a few ulp of the largest term."""
+    ref = oracle.build_model(1, 3, "galaxy", 4099)
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 4099))
+    nb.configure_all_pairs(1, 1)
+    dev.all_pairs_force()
+    nb.configure_all_pairs(0, 0)
+    oracle.all_pairs_force(ref)
+    assert maxrel(dev.download().a, ref.a) <= 2e-15
+
+
+def test_shard_windows_are_bitwise_identical(nb):
+    """Multi-GPU property on one GPU: any split of the targets into shard windows gives bitwise the full result."""
+    n = 6000
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    dev.all_pairs_force()
+    full = dev.download().a.copy()
+    for parts in (2, 4, 8, 7):
+        edges = [n * r // parts for r in range(parts + 1)]
+        hs0 = nb.build_model(1, 3, "galaxy", n)
+        d2 = nb.DeviceSystem.from_host(hs0)
+        for f, e in zip(edges[:-1], edges[1:]):
+            d2.all_pairs_force(f, e - f)
+        assert np.array_equal(d2.download().a, full), parts
+        d2.close()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_accelerate_step_bit_exact(nb, oracle, dtype, dim):
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 1000, 100003):
+        hs = nb.build_model(dtype, dim, "uniform", n)
+        hs.a[:] = rng.standard_normal(hs.a.shape)
+        hs.ao[:] = rng.standard_normal(hs.a.shape)
+        ref = oracle.State(dtype, dim, n)
+        for k in ("m", "x", "v", "a", "ao"):
+            getattr(ref, k)[:] = getattr(hs, k)
+        ref.dt, ref.c = hs.dt, hs.c
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.accelerate_step()
+        out = dev.download()
+        oracle.accelerate_step(ref)
+        for k in ("x", "v", "a", "ao"):
+            assert np.array_equal(getattr(out, k), getattr(ref, k)), (n, k)
+        dev.close()
+
+
+def test_trajectories_vs_reference_fixtures(nb, golden_positions):
+    """positions.bin frames written by the real reference (--save pos --csv-detailed) for all-pairs cases."""
+    meta, data = golden_positions
+    ran = 0
+    for name, case in meta.items():
+        if case["algorithm"] != "all-pairs":
+            continue
+        dtype = DT[case["precision"]]
+        ref = data[name + "__frames"]
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, case["dim"], case["workload"], case["n"]))
+        scale = np.abs(ref[0]).max()
+        k = 1
+        for step in range(1, case["steps"] + 1):
+            nb.run(dev, "all-pairs", 1)
+            if step in case["frame_ids"]:
+                x = dev.download().x
+                assert np.abs(x - ref[k]).max() <= TRAJ_TOL[dtype] * scale, (name, step)
+                k += 1
+        dev.close()
+        ran += 1
+    assert ran >= 25
+
+
+def test_print_state_text_double_exact(nb, oracle, golden_print_state):
+    """north_star: --print-state output matches the reference exactly (double, small N): all-pairs cases,
+    default mode => max(steps, 10) steps."""
+    ran = 0
+    for name, case in golden_print_state.items():
+        if case["algorithm"] != "all-pairs" or case["precision"] != "double":
+            continue
+        hs = nb.build_model(1, case["dim"], case["workload"], case["n"])
+        dev = nb.DeviceSystem.from_host(hs)
+        nb.run(dev, "all-pairs", nb.executed_steps(case["steps"], False))
+        out = dev.download()
+        s = oracle.State(1, case["dim"], hs.n)
+        for k in ("m", "x", "v", "a", "ao"):
+            getattr(s, k)[:] = getattr(out, k)
+        rows = oracle.format_state_rows(s)
+        diff = [i for i, (r, g) in enumerate(zip(rows, case["final"])) if r != g]
+        assert not diff, f"{name}: {len(diff)} rows differ, first: {rows[diff[0]]} vs {case['final'][diff[0]]}"
+        dev.close()
+        ran += 1
+    assert ran >= 12
+
+
+def test_config1_2d_float_n10000(nb, oracle):
+    """BASELINE config[0]: all-pairs 2D float -n 10000 -s 5 (=> 10 steps). Float tolerance on the trajectory."""
+    ref = oracle.build_model(0, 2, "uniform", 10000)
+    dev = nb.DeviceSystem.from_host(nb.build_model(0, 2, "uniform", 10000))
+    nsteps = nb.executed_steps(5, False)
+    nb.run(dev, "all-pairs", nsteps)
+    oracle.run(ref, "all-pairs", nsteps)
+    out = dev.download()
+    assert np.abs(out.x - ref.x).max() <= TRAJ_TOL[0] * np.abs(ref.x).max()
+    assert maxrel(out.a, ref.a) <= 50 * FORCE_TOL[0]  # 10 chaotic float steps
+
+
+def _sample_check(nb, oracle, dtype, dim, wl, n, algo, nsample=192, tol=None):
+    """Full-size run on the GPU; a random sample of targets is recomputed by the oracle against all n sources."""
+    hs = nb.build_model(dtype, dim, wl, n)
+    dev = nb.DeviceSystem.from_host(hs)
+    getattr(dev, algo)()
+    out = dev.download()
+    rng = np.random.default_rng(11)
+    ref = oracle.State(dtype, dim, hs.n)
+    for k in ("m", "x", "v"):
+        getattr(ref, k)[:] = getattr(hs, k)
+    ref.c, ref.dt = hs.c, hs.dt
+    picks = np.unique(np.concatenate([rng.integers(0, hs.n, nsample), [0, hs.n // 2, hs.n - 1]]))
+    scale = 0.0
+    worst = 0.0
+    for i in picks:
+        oracle.all_pairs_force(ref, int(i), 1)
+    scale = np.abs(ref.a[picks]).max()
+    worst = np.abs(out.a[picks] - ref.a[picks]).max() / scale
+    assert worst <= (tol or FORCE_TOL[dtype]), worst
+    return hs, dev, out
+
+
+def test_config2_full_size_properties(nb, oracle):
+    """BASELINE config[1]: 3D double N=65536.  Oracle on a target sample + size-independent properties:
+    total momentum change sum(m_i a_i) = 0 (Newton's third law) and exact linearity in the masses."""
+    hs, dev, out = _sample_check(nb, oracle, 1, 3, "galaxy", 65536, "all_pairs_force")
+    mom = (hs.m[:, None] * out.a).sum(axis=0)
+    assert np.abs(mom).max() <= 1e-10 * np.abs(hs.m[:, None] * out.a).sum()
+    hs2 = nb.build_model(1, 3, "galaxy", 65536)
+    hs2.m *= 2.0  # power of two: every product scales exactly
+    d2 = nb.DeviceSystem.from_host(hs2)
+    d2.all_pairs_force()
+    assert np.array_equal(d2.download().a, 2.0 * out.a)
+
+
+def test_config5_n_2pow20_sample(nb, oracle):
+    """BASELINE metric size: 3D double N=2^20 on one GPU, oracle on a target sample."""
+    _sample_check(nb, oracle, 1, 3, "galaxy", 1 << 20, "all_pairs_force", nsample=64)
+
+
+def test_edge_cases(nb):
+    hs = nb.HostSystem(1, 3, 4)
+    hs.m[:] = [1, 2, 3, 0]
+    hs.x[:] = [[0, 0, 0], [0, 0, 0], [1, 0, 0], [5, 5, 5]]  # coincident pair, zero-mass body
+    hs.c, hs.dt = 1.0, 0.1
+    dev = nb.DeviceSystem.from_host(hs)
+    dev.all_pairs_force()
+    a = dev.download().a
+    assert np.all(np.isfinite(a))
+    expect = 3.0 / (1.0 + np.finfo(np.float64).eps)
+    assert abs(a[0, 0] - expect) <= 4e-16 * expect and a[0, 0] == a[1, 0] and a[0, 1] == 0 and a[0, 2] == 0
+    one = nb.HostSystem(0, 2, 1)
+    one.m[:] = 1
+    one.c = 1.0
+    d1 = nb.DeviceSystem.from_host(one)
+    d1.all_pairs_force()
+    d1.all_pairs_collapsed_force()
+    assert not d1.download().a.any()
+
+
+# ---- K2 -------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_collapsed_force_vs_oracle(nb, oracle, dtype, dim):
+    """Intended semantics (all D components, 64-bit pair space) == all-pairs up to rounding; a - ao reset included."""
+    for wl, n in (("uniform", 2), ("uniform", 65), ("galaxy", 1000), ("uniform", 4099)):
+        ref = oracle.build_model(dtype, dim, wl, n)
+        hs = nb.build_model(dtype, dim, wl, n)
+        rng = np.random.default_rng(3)
+        hs.a[:] = rng.standard_normal(hs.a.shape)
+        hs.ao[:] = hs.a  # steady state of the driver: ao == a after accelerate_step
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.all_pairs_collapsed_force()
+        oracle.all_pairs_force(ref)
+        assert maxrel(dev.download().a, ref.a) <= 4 * FORCE_TOL[dtype], (wl, n)
+        dev.close()
+
+
+def test_collapsed_vs_reference_as_written_2d(nb, golden_positions):
+    """D=2, N < 65536: the reference's own collapsed output is well defined; match its frames."""
+    meta, data = golden_positions
+    ran = 0
+    for name, case in meta.items():
+        if case["algorithm"] != "all-pairs-collapsed" or case["dim"] != 2:
+            continue
+        dtype = DT[case["precision"]]
+        ref = data[name + "__frames"]
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 2, case["workload"], case["n"]))
+        for step in range(1, case["steps"] + 1):
+            nb.run(dev, "all-pairs-collapsed", 1)
+            assert np.abs(dev.download().x - ref[step]).max() <= TRAJ_TOL[dtype] * np.abs(ref[0]).max(), (name, step)
+        ran += 1
+    assert ran >= 2
+
+
+def test_config3_collapsed_3d_float_262144(nb, oracle):
+    """BASELINE config[2]: the reference computes nothing here (pair count wraps to 0); parity is pinned to
+    all-pairs on a target sample."""
+    _sample_check(nb, oracle, 0, 3, "uniform", 262144, "all_pairs_collapsed_force", nsample=64, tol=1e-4)

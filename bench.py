@@ -56,8 +56,15 @@ def cpu_baseline(n, hs, target_seconds=15.0):
         import oracle as O
         O.lib()
         so, build = O.LIB_PATH, "gcc -O2 -fopenmp"
-    L = C.CDLL(so)
     cores = len(os.sched_getaffinity(0))
+    try:  # respect the container's CPU quota (cgroup v2 cpu.max = "<quota> <period>")
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(quota) // int(period)))
+    except Exception:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(cores)
+    L = C.CDLL(so)
     a = np.zeros((n, 3), np.float64)
 
     def run(count):

@@ -45,7 +45,7 @@ ABI_SYMBOLS = [
     "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
     "nbody_accelerate_step", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
-    "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_nnodes", "nbody_create",
+    "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
 ]
 
@@ -171,6 +171,10 @@ class Bvh:
 
     def compute_force(self, st, theta, stream=None):
         _check(lib().nbody_bvh_compute_force(self.h, C.byref(st), C.c_double(theta), C.c_void_p(stream)))
+
+    def set_traversal(self, mode):
+        """0 auto, 1 per-lane walks, 2 wave-cooperative sweep (bitwise identical results)."""
+        _check(lib().nbody_bvh_set_traversal(self.h, mode))
 
     def enable_counters(self, on=True):
         _check(lib().nbody_bvh_enable_counters(self.h, 1 if on else 0))

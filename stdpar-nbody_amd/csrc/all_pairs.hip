@@ -180,7 +180,9 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-constexpr int kColTileJ = 1024;  // sources per LDS tile (16 per lane)
+// sources per LDS tile: 16 per lane in f32, 8 per lane in f64 (64 VGPRs of source registers either way)
+template <typename T>
+constexpr int kColTileJ = sizeof(T) == 4 ? 1024 : 512;
 
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void collapsed_reset_kernel(T* __restrict__ a, const T* __restrict__ ao, uint64_t n) {
@@ -213,8 +215,9 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
                                                                      T* __restrict__ a, T c, uint32_t sz,
                                                                      uint32_t tiles_per_block) {
   using rec_t = src_rec<T, D>;
-  constexpr int KJ = kColTileJ / 64;
-  __shared__ rec_t tile[kColTileJ];
+  constexpr int TJ = kColTileJ<T>;
+  constexpr int KJ = TJ / 64;
+  __shared__ rec_t tile[TJ];
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -231,16 +234,16 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
   }
   const int ntargets = (i0 < sz) ? int(min(64u, sz - i0)) : 0;  // wave-uniform
 
-  const uint32_t ntiles = (sz + kColTileJ - 1) / kColTileJ;
+  const uint32_t ntiles = (sz + TJ - 1) / TJ;
   const uint32_t t0     = blockIdx.y * tiles_per_block;
   const uint32_t t1     = min(ntiles, t0 + tiles_per_block);
 
   for (uint32_t t = t0; t < t1; ++t) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < kColTileJ / kBlock; ++q) {
+    for (int q = 0; q < TJ / kBlock; ++q) {
       uint32_t slot = q * kBlock + threadIdx.x;
-      uint64_t j    = uint64_t(t) * kColTileJ + slot;
+      uint64_t j    = uint64_t(t) * TJ + slot;
       rec_t r;
       if (j < sz) {
 #pragma unroll
@@ -293,7 +296,7 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
                      static_cast<T*>(s->a), static_cast<const T*>(s->ao), nelem);
   NB_HIP(hipGetLastError());
   uint32_t iblocks = (s->sz + kWaves * 64 - 1) / (kWaves * 64);
-  uint32_t ntiles  = (s->sz + kColTileJ - 1) / kColTileJ;
+  uint32_t ntiles  = (s->sz + kColTileJ<T> - 1) / kColTileJ<T>;
   // aim for >= 4096 blocks (16 per CU) while keeping >= 1 tile per block
   uint32_t ysplit = (4096 + iblocks - 1) / iblocks;
   if (ysplit > ntiles) ysplit = ntiles;

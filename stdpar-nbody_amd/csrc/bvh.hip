@@ -7,9 +7,10 @@
 //   idx[2]    u32[n] x2         ping-pong payload (original body index); the final one is the permutation
 //   hist      u32[256*nblk]     per-(digit, block) counts -> exclusive offsets
 //   tmp       T[n*(4D+1)]       gather scratch for the in-place permutation of m,x,v,a,ao
-//   node      rec[nnodes]       one power-of-two sized record per node: COM (D), mass, width.
-//                               The traversal touches exactly one record per node test (the reference
-//                               keeps m/bw/b in three arrays, src/bvh.h:103-106).
+//   node      rec[nnodes+nleafs/2]  one 8-scalar record per internal node (COM, mass, width, width^2) followed by
+//                               one per leaf PAIR (both bodies' position+mass), so the traversal touches
+//                               exactly one aligned record per step (the reference keeps m/bw/b in three
+//                               arrays and reads bodies from x and m, src/bvh.h:103-106,294-295).
 //   box       T[nnodes*2D]      node AABBs, only used by the build
 // Everything integer (keys, sort, permutation, traversal decisions, node visit counts) is bit-exact
 // against the oracle; tree COMs/widths are bit-exact too (FP contraction is off in the build and in
@@ -23,11 +24,13 @@ namespace nbody {
 
 constexpr int kB = 256;
 
-template <typename T, int D>
-struct alignas(((D + 2) * sizeof(T) <= 16) ? 16 : ((D + 2) * sizeof(T) <= 32 ? 32 : 64)) node_rec {
-  T p[D];
-  T mass;
-  T bw;
+// One 8-scalar record (32 B f32 / 64 B f64) per tree entry, so every traversal step is ONE aligned load:
+//   internal node i (i < nnodes):   v[0..D-1] centre of mass, v[D] mass, v[D+1] width, v[D+2] width^2
+//   leaf pair k (index nnodes + k): v[0..D-1] x[2k], v[D] m[2k], v[D+1..2D] x[2k+1], v[2D+1] m[2k+1]
+//                                   (an absent body 2k+1 >= N is stored as zeros: mass 0 contributes exactly 0)
+template <typename T>
+struct alignas(sizeof(T) * 8) tree_rec {
+  T v[8];
 };
 
 }  // namespace nbody
@@ -47,6 +50,7 @@ struct nbody_bvh {
   void* box       = nullptr;
   uint32_t* counters = nullptr;
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
+  int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
 };
 
@@ -368,55 +372,61 @@ __device__ __forceinline__ T node_width(const T* b) {  // src/bvh.h:140-144, std
 
 template <typename T, int D>
 __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restrict__ m, const T* __restrict__ x, uint32_t nbodies,
-                                                              uint32_t first, uint32_t count, node_rec<T, D>* __restrict__ node,
-                                                              T* __restrict__ box) {
+                                                              uint32_t first, uint32_t count, uint32_t nnodes,
+                                                              tree_rec<T>* __restrict__ node, T* __restrict__ box) {
 #pragma clang fp contract(off)
   uint32_t li = blockIdx.x * kB + threadIdx.x;
   if (li >= count) return;
   const uint32_t i  = first + li;
   const uint64_t bl = uint64_t(li) * 2, br = bl + 1;
   const T tol = T(double(sizeof(T) == 4 ? double(FLT_EPSILON) : DBL_EPSILON) * 10.);
-  node_rec<T, D> r;
-  T* b = box + uint64_t(i) * 2 * D;
-  if (bl >= nbodies) {  // dead node (src/bvh.h:185-188); box/width are don't-care in the reference, 0 here
+  tree_rec<T> r, pair;
 #pragma unroll
-    for (int k = 0; k < D; ++k) r.p[k] = T(0);
-    r.mass = T(0);
-    r.bw   = T(0);
+  for (int k = 0; k < 8; ++k) r.v[k] = pair.v[k] = T(0);
+  T* b = box + uint64_t(i) * 2 * D;
+  if (bl >= nbodies) {  // dead node (src/bvh.h:185-188): mass 0; box/width are don't-care in the reference, 0 here
 #pragma unroll
     for (int k = 0; k < 2 * D; ++k) b[k] = T(0);
   } else if (br >= nbodies) {  // single body (src/bvh.h:190-194)
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      T p      = x[bl * D + k];
-      r.p[k]   = p;
-      b[k]     = p - tol;
-      b[D + k] = p + tol;
+      T p       = x[bl * D + k];
+      r.v[k]    = p;
+      pair.v[k] = p;
+      b[k]      = p - tol;
+      b[D + k]  = p + tol;
     }
-    r.mass = m[bl];
-    r.bw   = node_width<T, D>(b);
+    r.v[D]     = m[bl];
+    pair.v[D]  = r.v[D];
+    r.v[D + 1] = node_width<T, D>(b);
   } else {  // two bodies (src/bvh.h:195-205)
     const T ml = m[bl], mr = m[br];
     const T mass = ml + mr;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       T p0 = x[bl * D + k], p1 = x[br * D + k];
-      T com    = ml * p0 + mr * p1;
-      r.p[k]   = com / mass;
-      b[k]     = fmin_(p0, p1) - tol;
-      b[D + k] = fmax_(p0, p1) + tol;
+      T com             = ml * p0 + mr * p1;
+      r.v[k]            = com / mass;
+      pair.v[k]         = p0;
+      pair.v[D + 1 + k] = p1;
+      b[k]              = fmin_(p0, p1) - tol;
+      b[D + k]          = fmax_(p0, p1) + tol;
     }
-    r.mass = mass;
-    r.bw   = node_width<T, D>(b);
+    r.v[D]            = mass;
+    pair.v[D]         = ml;
+    pair.v[2 * D + 1] = mr;
+    r.v[D + 1]        = node_width<T, D>(b);
   }
-  node[i] = r;
+  r.v[D + 2]                   = r.v[D + 1] * r.v[D + 1];  // the product the opening test needs, rounded once
+  node[i]                      = r;
+  node[uint64_t(nnodes) + li] = pair;
 }
 
 // Levels [l_hi ... l_lo] (descending), one launch.  Levels with more than one block's worth of nodes
 // are launched one per kernel (l_hi == l_lo); the top of the tree (<= kB nodes per level) is built
 // by a single block looping over levels with a barrier in between.
 template <typename T, int D>
-__global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_lo, node_rec<T, D>* __restrict__ node,
+__global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_lo, tree_rec<T>* __restrict__ node,
                                                                 T* __restrict__ box) {
 #pragma clang fp contract(off)
   for (int l = l_hi; l >= l_lo; --l) {
@@ -424,47 +434,86 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
     for (uint32_t li = blockIdx.x * kB + threadIdx.x; li < count; li += gridDim.x * kB) {
       const uint32_t i  = first + li;
       const uint32_t bl = li * 2 + first + count, br = bl + 1;
-      const node_rec<T, D> ml = node[bl];
-      const node_rec<T, D> mr = node[br];
-      node_rec<T, D> r;
+      const tree_rec<T> ml = node[bl];
+      const tree_rec<T> mr = node[br];
+      tree_rec<T> r;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) r.v[k] = T(0);
       T* b = box + uint64_t(i) * 2 * D;
-      if (!(ml.mass != T(0))) {  // left dead (src/bvh.h:225-228): copy left monopole
-        r    = ml;
-        r.bw = T(0);
+      if (!(ml.v[D] != T(0))) {  // left dead (src/bvh.h:225-228): copy left monopole (all zeros)
+#pragma unroll
+        for (int k = 0; k <= D; ++k) r.v[k] = ml.v[k];
 #pragma unroll
         for (int k = 0; k < 2 * D; ++k) b[k] = T(0);
-      } else if (!(mr.mass != T(0))) {  // right dead (src/bvh.h:230-233): copy left node entirely
+      } else if (!(mr.v[D] != T(0))) {  // right dead (src/bvh.h:230-233): copy left node entirely
         r = ml;
 #pragma unroll
         for (int k = 0; k < 2 * D; ++k) b[k] = box[uint64_t(bl) * 2 * D + k];
       } else {  // src/bvh.h:234-241
-        const T mass = ml.mass + mr.mass;
+        const T mass = ml.v[D] + mr.v[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-          r.p[k]   = (ml.mass * ml.p[k] + mr.mass * mr.p[k]) / mass;
+          r.v[k]   = (ml.v[D] * ml.v[k] + mr.v[D] * mr.v[k]) / mass;
           b[k]     = fmin_(box[uint64_t(bl) * 2 * D + k], box[uint64_t(br) * 2 * D + k]);
           b[D + k] = fmax_(box[uint64_t(bl) * 2 * D + D + k], box[uint64_t(br) * 2 * D + D + k]);
         }
-        r.mass = mass;
-        r.bw   = node_width<T, D>(b);
+        r.v[D]     = mass;
+        r.v[D + 1] = node_width<T, D>(b);
+        r.v[D + 2] = r.v[D + 1] * r.v[D + 1];
       }
       node[i] = r;
     }
-    if (l > l_lo) __syncthreads();  // single-block multi-level mode only
+    if (l > l_lo) {
+      __threadfence_block();
+      __syncthreads();  // single-block multi-level mode only
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9 traversal  (src/bvh.h:246-324)
-// One lane per body (bodies are Hilbert-sorted, so the 64 lanes of a wave walk nearly the same
-// path and their node records coalesce into a few L2 lines).  Bound: L2/HBM latency-bandwidth of the
-// node-record gather + FP64 VALU of the accepted terms.
+// K9 traversal  (src/bvh.h:246-324), per-lane form: the reference's loop as is, one independent stackless
+// walk per lane.  Kept as the n > 2^26 fallback and as the cross-check of the wave-cooperative form.
+// Its weakness on a GPU: lanes drift apart in the tree, so node loads become fully divergent.
 // ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__device__ __forceinline__ void accumulate_leaf_pair(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& rc) {
+  src_rec<T, D> sa, sb;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    sa.p[k] = rc.v[k];
+    sb.p[k] = rc.v[D + 1 + k];
+  }
+  sa.m = rc.v[D];
+  sb.m = rc.v[2 * D + 1];
+  pair_accumulate<T, D>(acc, xs, sa);  // the self pair and an absent second body add exactly 0
+  pair_accumulate<T, D>(acc, xs, sb);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ bool can_approximate(const T (&xs)[D], const tree_rec<T>& nd, T theta2) {
+#pragma clang fp contract(off)
+  T d2 = T(0);  // dist2(xs, xj), src/vec.h:232-240: separate multiply and add, in the reference's order
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    T di = xs[k] - nd.v[k];
+    d2   = d2 + di * di;
+  }
+  return nd.v[D + 2] < theta2 * d2;  // bw*bw < theta^2 * dist2, src/bvh.h:246-248
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void accumulate_monopole(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& nd) {
+  src_rec<T, D> s;
+#pragma unroll
+  for (int k = 0; k < D; ++k) s.p[k] = nd.v[k];
+  s.m = nd.v[D];
+  pair_accumulate<T, D>(acc, xs, s);
+}
+
 template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void bvh_force_kernel(const node_rec<T, D>* __restrict__ node, const T* __restrict__ m,
-                                                       const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
-                                                       uint32_t first, uint32_t count, T theta2, uint32_t nlevels,
-                                                       uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
+                                                       T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
+                                                       uint32_t nlevels, uint32_t nnodes, uint32_t* __restrict__ counters) {
   const uint32_t local = blockIdx.x * 64 + threadIdx.x;
   if (local >= count) return;
   const uint32_t i = first + local;
@@ -481,44 +530,22 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const node_rec<T, D>* __r
 
   while (covered < sz) {
     if (level == leaf_level) {  // src/bvh.h:288-303
-      uint32_t bidx = tree_index - leaf_first;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        if (bidx < sz) {  // the self pair contributes exactly 0 (common.hpp), no `bidx != i` test needed
-          src_rec<T, D> s;
-#pragma unroll
-          for (int k = 0; k < D; ++k) s.p[k] = x[uint64_t(bidx) * D + k];
-          s.m = m[bidx];
-          pair_accumulate<T, D>(acc, xs, s);
-          if (COUNT && bidx != i) ++c_body;
-        }
-        ++bidx;
+      const uint32_t bidx  = tree_index - leaf_first;
+      const tree_rec<T> rc = node[uint64_t(nnodes) + (bidx >> 1)];
+      accumulate_leaf_pair<T, D>(acc, xs, rc);
+      if (COUNT) {
+        c_body += (bidx != i) + uint32_t(bidx + 1 < sz && bidx + 1 != i);
+        ++c_leaf;
       }
       covered += 2;
-      if (COUNT) ++c_leaf;
       // force_ascend_right: parent + 1 (src/bvh.h:272-275, :115-120)
       tree_index = ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
       level -= 1;
     } else {
-      const node_rec<T, D> nd = node[tree_index];
+      const tree_rec<T> nd = node[tree_index];
       if (COUNT) ++c_nodes;
-      bool approx;
-      {
-#pragma clang fp contract(off)
-        T d2 = T(0);  // dist2(xs, xj), src/vec.h:232-240: separate multiply and add
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          T di = xs[k] - nd.p[k];
-          d2   = d2 + di * di;
-        }
-        approx = nd.bw * nd.bw < theta2 * d2;  // can_approximate, src/bvh.h:246-248
-      }
-      if (approx) {
-        src_rec<T, D> s;
-#pragma unroll
-        for (int k = 0; k < D; ++k) s.p[k] = nd.p[k];
-        s.m = nd.mass;
-        pair_accumulate<T, D>(acc, xs, s);
+      if (can_approximate<T, D>(xs, nd, theta2)) {
+        accumulate_monopole<T, D>(acc, xs, nd);
         if (COUNT) ++c_mono;
         covered += 1u << (nlevels - level);
         if ((tree_index - 1u) & 1u) {  // right child -> parent + 1 (src/bvh.h:277-281)
@@ -541,6 +568,115 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const node_rec<T, D>* __r
     counters[uint64_t(i) * 4 + 1] = c_leaf;
     counters[uint64_t(i) * 4 + 2] = c_mono;
     counters[uint64_t(i) * 4 + 3] = c_body;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9, wave-cooperative form (default).
+//
+// Every lane still performs exactly the reference's own sequence of node tests / leaf visits, in its own
+// order, with its own decisions (results and counters are bitwise those of bvh_force_kernel).  What
+// changes is WHEN: a lane's state is the key (covered, level) of the node it must visit next — `covered`
+// = index of the node's first leaf — and along any lane's walk that key only grows in (covered, level)
+// lexicographic order, which is DFS pre-order.  The wave therefore sweeps the UNION of its 64 lanes' nodes
+// once, in key order: at each step the record is wave-uniform (one scalar load instead of 64 divergent
+// gathers), lanes whose key equals the current one take part, the others wait.  Lanes can no longer drift
+// apart.  Union per wave at config 4: ~7.5k node tests vs ~4.2k per lane.
+//
+// The walk is a serial chain (decision -> next record -> decision); its latency is hidden by the other waves
+// of the SIMD (8 resident).  Speculatively fetching both possible successors was measured and is WORSE
+// (26 vs 14 ms at config 4): scalar loads return out of order, so each step would wait for the not-taken
+// successor too, which is often a cold miss.
+// Packed key = covered << 5 | level, so this form needs nlevels <= 26.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
+                                                            const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
+                                                            uint32_t count, T theta2, uint32_t nlevels, uint32_t nnodes,
+                                                            uint32_t* __restrict__ counters) {
+  constexpr uint32_t DONE = 0xffffffffu;
+  const uint32_t local = blockIdx.x * 64 + threadIdx.x;
+  const bool valid     = local < count;
+  const uint32_t i     = first + (valid ? local : 0u);
+  T xs[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xs[k]  = x[uint64_t(i) * D + k];
+    acc[k] = T(0);
+  }
+  uint32_t key              = valid ? 0u : DONE;  // root: covered 0, level 0
+  const uint32_t leaf_level = nlevels;
+  uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
+
+  // record index of a key (wave-uniform)
+  auto rec_index = [&](uint32_t k) -> uint64_t {
+    const uint32_t lv = k & 31u, cv = k >> 5;
+    return lv == leaf_level ? uint64_t(nnodes) + (cv >> 1) : uint64_t(((1u << lv) - 1u) + (cv >> (nlevels - lv)));
+  };
+
+  uint32_t cur = 0;
+
+  for (;;) {
+    cur                  = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; pin it to an SGPR
+    const uint32_t level = cur & 31u, cov = cur >> 5;
+    if (cov >= sz) break;  // every remaining key is >= cur: all lanes are finished
+    const bool leaf      = level == leaf_level;
+    const tree_rec<T> rc = node[rec_index(cur)];  // wave-uniform address: one scalar load
+
+    // keys of the two possible successors
+    const uint32_t idx  = leaf ? 0u : ((1u << level) - 1u) + (cov >> (nlevels - level));
+    const uint32_t ncov = cov + (leaf ? 2u : (1u << (nlevels - level)));
+    // leaf -> parent + 1 (level - 1); left child -> sibling (same level); right child -> parent + 1  (src/bvh.h:272-281)
+    const uint32_t nlev = (leaf || ((idx - 1u) & 1u)) ? level - 1u : level;
+    const uint32_t ka   = (ncov >= sz) ? DONE : ((ncov << 5) | (nlev & 31u));
+    const uint32_t kd   = cur + 1u;  // descend: same covered, level + 1  (src/bvh.h:283-286)
+
+    const bool active = key == cur;
+    bool any_reject   = false;
+    if (leaf) {  // src/bvh.h:288-303
+      if (active) {
+        accumulate_leaf_pair<T, D>(acc, xs, rc);
+        if (COUNT) {
+          c_body += (cov != i) + uint32_t(cov + 1 < sz && cov + 1 != i);
+          ++c_leaf;
+        }
+        key = ka;
+      }
+    } else {
+      const bool approx = can_approximate<T, D>(xs, rc, theta2);
+      const bool accept = active && approx;
+      const bool reject = active && !approx;
+      if (COUNT && active) ++c_nodes;
+      if (accept) {
+        accumulate_monopole<T, D>(acc, xs, rc);
+        if (COUNT) ++c_mono;
+        key = ka;
+      }
+      if (reject) key = kd;
+      any_reject = __ballot(reject) != 0ull;
+    }
+    if (any_reject) {
+      cur = kd;  // the left child is the smallest key any lane can now hold
+    } else {
+      // smallest key held by any lane: start from the finishing lanes' key, refine while some lane is behind it
+      uint32_t cand   = ka;
+      uint64_t behind = __ballot(key < cand);
+      while (behind) {
+        cand   = __builtin_amdgcn_readlane(key, __builtin_ctzll(behind));
+        behind = __ballot(key < cand);
+      }
+      cur = cand;
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(i) * 4 + 0] = c_nodes;
+      counters[uint64_t(i) * 4 + 1] = c_leaf;
+      counters[uint64_t(i) * 4 + 2] = c_mono;
+      counters[uint64_t(i) * 4 + 3] = c_body;
+    }
   }
 }
 
@@ -610,12 +746,12 @@ static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
 
 template <typename T, int D>
 static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
-  auto* node         = static_cast<node_rec<T, D>*>(t->node);
+  auto* node         = static_cast<tree_rec<T>*>(t->node);
   T* box             = static_cast<T*>(t->box);
   const int last     = int(t->nlevels) - 1;
   const uint32_t cnt = 1u << last;
   hipLaunchKernelGGL((build_leaf_level_kernel<T, D>), dim3((cnt + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, node, box);
+                     static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, t->nnodes, node, box);
   NB_HIP(hipGetLastError());
   int l = last - 1;
   for (; l >= 0 && (1u << l) > uint32_t(kB); --l) {
@@ -635,15 +771,24 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th  = static_cast<T>(theta);
   const T th2 = th * th;  // src/bvh.h:252, in T
   const uint32_t blocks = (s->count + 63) / 64;
-  auto* node = static_cast<const node_rec<T, D>*>(t->node);
-  if (t->counters_on)
-    hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), dim3(blocks), dim3(64), 0, st, node, static_cast<const T*>(s->m),
-                       static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, th2,
-                       t->nlevels, t->counters);
-  else
-    hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), dim3(blocks), dim3(64), 0, st, node, static_cast<const T*>(s->m),
-                       static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, th2,
-                       t->nlevels, t->counters);
+  auto* node = static_cast<const tree_rec<T>*>(t->node);
+  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26);
+  if (wave && t->nlevels > 26) {
+    set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
+    return NBODY_ERR_ARG;
+  }
+#define NB_LAUNCH(KERN, CNT)                                                                                                 \
+  hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a),                          \
+                     static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, s->count, th2, t->nlevels, t->nnodes, \
+                     t->counters)
+  if (wave) {
+    if (t->counters_on) NB_LAUNCH(bvh_force_wave_kernel, true);
+    else NB_LAUNCH(bvh_force_wave_kernel, false);
+  } else {
+    if (t->counters_on) NB_LAUNCH(bvh_force_kernel, true);
+    else NB_LAUNCH(bvh_force_kernel, false);
+  }
+#undef NB_LAUNCH
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -675,8 +820,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   t->bbox_blocks = (n + kB * 8 - 1) / (kB * 8);
   if (t->bbox_blocks > 1024) t->bbox_blocks = 1024;
   const size_t D = size_t(dim);
-  size_t rb      = (D + 2) * t->tsz;
-  t->rec_bytes   = rb <= 16 ? 16 : (rb <= 32 ? 32 : 64);
+  t->rec_bytes   = 8 * t->tsz;  // tree_rec<T>
   // tmp doubles as a radix key buffer (u64[n]) and as the gather scratch (T[n*(4D+1)])
   size_t tmp_bytes = t->tsz * size_t(n) * (4 * D + 1);
   if (tmp_bytes < sizeof(uint64_t) * size_t(n)) tmp_bytes = sizeof(uint64_t) * size_t(n);
@@ -698,7 +842,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * size_t(t->sort_blocks));
   NB_ALLOC(t->tmp, tmp_bytes);
-  NB_ALLOC(t->node, t->rec_bytes * size_t(t->nnodes));
+  NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs / 2)));  // internal nodes + leaf pairs
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
 #undef NB_ALLOC
   *out = t;
@@ -727,6 +871,13 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
   if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 4 * size_t(t->n)));
   t->counters_on = on != 0;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
+  NB_ARG(t != nullptr, "nbody_bvh is NULL");
+  NB_ARG(mode >= 0 && mode <= 2, "traversal mode must be 0 (auto), 1 (per-lane) or 2 (wave-cooperative), got %d", mode);
+  t->traversal = mode;
   return NBODY_OK;
 }
 

@@ -96,19 +96,14 @@ struct pair_math<double> {
 template <>
 struct pair_math<float> {
   static constexpr float tiny = 1e-37f;
-  // returns mj / (r2 * sqrt(r2) + FLT_EPSILON); v_rsq_f32 / v_rcp_f32 are 1 ulp, one Newton step each
-  // keeps the term within ~1.5 ulp of the exact expression (the reference's own powf/divide chain
-  // is not reproducible across its builds at this level).
+  // returns mj / (r2 * sqrt(r2) + FLT_EPSILON).  v_rsq_f32 / v_rcp_f32 are 1-ulp instructions, so no polish:
+  // the term is within ~4 ulp (5e-7) of the exact expression, below the spread between the reference's own
+  // float builds (its powf/divide chain is not reproducible at this level) and far below the
+  // float parity tolerance (2e-5).  3 full-rate ops + 2 transcendentals.
   __device__ static __forceinline__ float weight(float r2, float mj) {
     float y0 = __builtin_amdgcn_rsqf(r2);
-    float h  = r2 * y0;
-    float e  = __builtin_fmaf(-h, y0, 1.0f);
-    float s  = __builtin_fmaf(h * 0.5f, e, h);
-    float d3 = __builtin_fmaf(r2, s, FLT_EPSILON);
-    float z0 = __builtin_amdgcn_rcpf(d3);
-    float e2 = __builtin_fmaf(-d3, z0, 1.0f);
-    float zm = z0 * mj;
-    return __builtin_fmaf(zm, e2, zm);
+    float d3 = __builtin_fmaf(r2, r2 * y0, FLT_EPSILON);
+    return __builtin_amdgcn_rcpf(d3) * mj;
   }
 };
 

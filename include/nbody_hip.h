@@ -81,6 +81,11 @@ int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream);
  *   x += dt*v + ((0.5*dt)*dt)*ao;  v += (0.5*dt)*(a + ao);  ao = a          (bit-exact, no FMA) */
 int nbody_accelerate_step(const nbody_state* s, void* stream);
 
+/* K10+K11. Replaces System::calc_energies (src/system.h:62-79): kinetic = 0.5*sum m|v|^2 and potential =
+ * -0.5*c*sum_i sum_{j!=i} m_i m_j/(|x_i-x_j| + eps).  Writes one T each to the HOST pointers; blocking.
+ * Needs the whole system (first = 0, count = sz). */
+int nbody_calc_energies(const nbody_state* s, void* kinetic_out, void* potential_out, void* stream);
+
 /* Tuning knob for K1 (does not change which pairs are summed, only the split of the source range
  * over the waves of a block and hence the rounding order).  split in {0 (auto from sz), 1, 2, 4};
  * targets_per_thread in {0 (auto), 1, 2}.  The auto choice depends on sz only — never on

@@ -43,7 +43,7 @@ def build(verbose=False):
 # every symbol include/nbody_hip.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
     "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
-    "nbody_accelerate_step", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
+    "nbody_accelerate_step", "nbody_calc_energies", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
     "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
@@ -258,6 +258,14 @@ class DeviceSystem:
     def accelerate_step(self, first=0, count=None):
         st = self.state(first, count)
         _check(lib().nbody_accelerate_step(C.byref(st), C.c_void_p(self.stream)))
+
+    def calc_energies(self):
+        """(kinetic, potential) as in System::calc_energies (src/system.h:62-79); blocking."""
+        t = np_dtype(self.dtype)
+        ke, pe = np.zeros(1, t), np.zeros(1, t)
+        st = self.state()
+        _check(lib().nbody_calc_energies(C.byref(st), _p(ke), _p(pe), C.c_void_p(self.stream)))
+        return ke[0], pe[0]
 
     # K4..K9
     @property

@@ -5,7 +5,7 @@
 //   bbox      T[3*D]            xmin, xmax (K4) and the grid cell size (K5's divisor)
 //   keys[2]   u64[n] x2         ping-pong radix-sort key buffers
 //   idx[2]    u32[n] x2         ping-pong payload (original body index); the final one is the permutation
-//   hist      u32[256*nblk]     per-(digit, block) counts -> exclusive offsets
+//   hist      u32[256*(nblk+1)] per-(digit, block) counts -> exclusive offsets per digit row, + 256 digit totals
 //   tmp       T[n*(4D+1)]       gather scratch for the in-place permutation of m,x,v,a,ao
 //   node      rec[nnodes+nleafs/2]  one 8-scalar record per internal node (COM, mass, width, width^2) followed by
 //                               one per leaf PAIR (both bodies' position+mass), so the traversal touches
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kB) void hilbert_keys_kernel(const T* __restrict__ 
 // K6 stable LSD radix sort of (key, index), 8 bits per pass  (replaces std::sort, src/bvh.h:55-94;
 // the reference sort is unstable, ties here keep original index order)
 // ------------------------------------------------------------------------------------------------
-constexpr int kSortIPT  = 8;
+constexpr int kSortIPT  = 8;  // keys per lane
 constexpr int kSortTile = kB * kSortIPT;  // 2048 keys per block; wave w owns keys [w*512, w*512+512)
 
 __global__ __launch_bounds__(kB) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
@@ -247,39 +247,43 @@ __global__ __launch_bounds__(kB) void radix_hist_kernel(const uint64_t* __restri
   hist[uint64_t(threadIdx.x) * nblk + blockIdx.x] = cnt[threadIdx.x];
 }
 
-// single-block exclusive scan over hist[total] (digit-major, block-minor)
-__global__ __launch_bounds__(1024) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t total) {
-  __shared__ uint32_t wsum[16];
-  const uint32_t per = (total + 1023u) / 1024u;
-  const uint32_t b   = threadIdx.x * per;
-  const uint32_t e   = min(total, b + per);
-  uint32_t s         = 0;
-  for (uint32_t i = b; i < e; ++i) s += hist[i];
-  // inclusive scan of s across the block
+// Exclusive scan of one digit's row hist[d][0..nblk) (one block per digit, coalesced) + the digit's total.
+// The scan ACROSS digits (256 totals) is folded into the scatter kernel, so a pass has no serial kernel.
+__global__ __launch_bounds__(kB) void radix_scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                             uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[kB / 64];
+  __shared__ uint32_t carry;
+  uint32_t* row  = hist + uint64_t(blockIdx.x) * nblk;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  uint32_t inc = s;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    uint32_t o = __shfl_up(inc, off, 64);
-    if (lane >= off) inc += o;
-  }
-  if (lane == 63) wsum[wave] = inc;
+  if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  uint32_t base = 0;
-  for (int w = 0; w < wave; ++w) base += wsum[w];
-  uint32_t run = base + inc - s;  // exclusive prefix of this thread's chunk
-  for (uint32_t i = b; i < e; ++i) {
-    uint32_t v = hist[i];
-    hist[i]    = run;
-    run += v;
+  for (uint32_t base = 0; base < nblk; base += kB) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblk ? row[i] : 0u;
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (i < nblk) row[i] = pre + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kB - 1) carry = pre + inc;
+    __syncthreads();
   }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
 __global__ __launch_bounds__(kB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ hist,
-                                                           uint32_t nblk) {
+                                                           const uint32_t* __restrict__ totals, uint32_t nblk) {
   __shared__ uint32_t wcnt[kB / 64][256];
+  __shared__ uint32_t dbase[256];  // exclusive scan of the 256 digit totals
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int q = threadIdx.x; q < (kB / 64) * 256; q += kB) (&wcnt[0][0])[q] = 0;
   __syncthreads();
@@ -309,10 +313,22 @@ __global__ __launch_bounds__(kB) void radix_scatter_kernel(const uint64_t* __res
     if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
     __builtin_amdgcn_wave_barrier();
   }
+  {  // digit = threadIdx.x: exclusive scan of totals[0..255]; within a wave here, wave offsets after the barrier
+    const uint32_t v = totals[threadIdx.x];
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    dbase[threadIdx.x] = inc - v;
+  }
   __syncthreads();
   // digit = threadIdx.x: turn per-wave counts into global bases
   {
-    uint32_t run = hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += dbase[w * 64 + 63] + totals[w * 64 + 63];  // totals of the earlier 64-digit groups
+    uint32_t run = woff + dbase[threadIdx.x] + hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < kB / 64; ++w) {
       uint32_t cw          = wcnt[w][threadIdx.x];
@@ -720,10 +736,10 @@ static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   for (int shift = 0; shift < key_bits; shift += 8) {
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], n, shift, t->hist, nblk);
     NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(radix_scan_kernel, dim3(1), dim3(1024), 0, st, t->hist, 256u * nblk);
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kB), 0, st, t->hist, nblk, t->hist + 256u * size_t(nblk));
     NB_HIP(hipGetLastError());
     hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], idx_in, kbuf[cur ^ 1], t->idx[cur ^ 1], n,
-                       shift, t->hist, nblk);
+                       shift, t->hist, t->hist + 256u * size_t(nblk), nblk);
     NB_HIP(hipGetLastError());
     cur ^= 1;
     idx_in = t->idx[cur];
@@ -840,7 +856,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->keys[1], sizeof(uint64_t) * size_t(n));
   NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
-  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * size_t(t->sort_blocks));
+  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(t->sort_blocks) + 1));  // + 256 digit totals
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs / 2)));  // internal nodes + leaf pairs
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));

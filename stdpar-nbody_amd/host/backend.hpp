@@ -4,6 +4,8 @@
 #include <cstdlib>
 #include <iostream>
 #include <type_traits>
+#include <utility>
+#include <vector>
 
 #include "nbody_hip.h"
 #include "system.hpp"
@@ -54,6 +56,13 @@ class Device {
     backend_check(nbody_all_pairs_collapsed_force(&view_, stream()), "nbody_all_pairs_collapsed_force");
   }
   void accelerate_step() { backend_check(nbody_accelerate_step(&view_, stream()), "nbody_accelerate_step"); }
+
+  // System::calc_energies (src/system.h:62-79) on the device: {kinetic, potential}
+  std::pair<T, T> calc_energies() {
+    T ke{}, pe{};
+    backend_check(nbody_calc_energies(&view_, &ke, &pe, stream()), "nbody_calc_energies");
+    return {ke, pe};
+  }
 
   void bvh_alloc() {
     if (!tree_) backend_check(nbody_bvh_create(&tree_, dtype, D, host_.n), "nbody_bvh_create");

@@ -26,9 +26,9 @@ class Saver {
       put(pos_file_, dim);
     }
     if (energy_) {
-      std::cerr << "--save energy needs System::calc_energies on the device, which this build does not provide yet"
-                << std::endl;
-      std::exit(EXIT_FAILURE);
+      energy_file_.open("energy.bin", std::ios::out | std::ios::binary);
+      put(energy_file_, nsteps_);
+      put(energy_file_, tsz);
     }
   }
 
@@ -36,9 +36,15 @@ class Saver {
 
   // one frame; the device copy is authoritative, so positions are pulled first
   void save_all(System<T, D>& sys, Device<T, D>& dev) {
-    if (!pos_) return;
-    dev.pull_positions();
-    pos_file_.write(reinterpret_cast<char const*>(sys.x.data()), std::streamsize(std::size_t(nbodies_) * sizeof(T) * D));
+    if (pos_) {
+      dev.pull_positions();
+      pos_file_.write(reinterpret_cast<char const*>(sys.x.data()), std::streamsize(std::size_t(nbodies_) * sizeof(T) * D));
+    }
+    if (energy_) {
+      auto [kinetic, potential] = dev.calc_energies();
+      put(energy_file_, kinetic);
+      put(energy_file_, potential);
+    }
   }
 
  private:
@@ -48,7 +54,7 @@ class Saver {
   }
   bool pos_, energy_;
   std::uint32_t nbodies_, nsteps_;
-  std::ofstream pos_file_;
+  std::ofstream pos_file_, energy_file_;
 };
 
 }  // namespace nb

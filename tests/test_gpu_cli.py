@@ -1,0 +1,119 @@
+"""GPU: the ISO-C++ CLI host (stdpar-nbody_amd/bin/nbody_hip_d{2,3}) end to end against the reference-generated
+fixtures: --print-state text, positions.bin / energy.bin, CSV rows and the step-count semantics."""
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import DT, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def cli(dim, args, cwd=None):
+    exe = os.path.join(ROOT, "stdpar-nbody_amd", "bin", f"nbody_hip_d{dim}")
+    return subprocess.run([exe] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_print_state_text_matches_reference(oracle, golden_print_state):
+    """Double precision: starting AND final rows are textually identical to the reference's stdout."""
+    ran = 0
+    for name, case in golden_print_state.items():
+        if case["precision"] != "double" or case["algorithm"] == "all-pairs-collapsed":
+            continue
+        r = cli(case["dim"], case["args"])
+        assert r.returncode == 0, r.stderr
+        start, final = oracle.parse_print_state(r.stdout)
+        assert start == case["start"], f"{name}: starting state"
+        bad = [i for i, (a, b) in enumerate(zip(final, case["final"])) if a != b]
+        assert len(final) == len(case["final"]) and not bad, f"{name}: {len(bad)} final rows differ"
+        assert "Starting simulation\n" in r.stdout and re.search(r"Done simulation\nTotal time: \d+\.\d\d ms\n", r.stdout)
+        ran += 1
+    assert ran >= 36
+
+
+def test_float_n10_text(oracle, golden_print_state):
+    """Float agrees textually only at toy N: the README check, -s 5 -n 10, D=2."""
+    for name, case in golden_print_state.items():
+        if case["precision"] == "float" and case["n"] == 10 and case["dim"] == 2 and case["algorithm"] != "all-pairs-collapsed":
+            r = cli(2, case["args"])
+            start, final = oracle.parse_print_state(r.stdout)
+            assert start == case["start"]
+            num = lambda rows: np.array([[float(v) for v in re.findall(r"[-+]?\d\.\d+e[-+]\d+", row)] for row in rows])
+            np.testing.assert_allclose(num(final), num(case["final"]), rtol=2e-3, atol=1e-9)
+
+
+def test_step_count_semantics():
+    """-s 1, 5, 10 all run 10 steps; -s 11 runs 11 (default mode warm-up, src/arguments.h:26, src/all_pairs.h:93-97)."""
+    outs = {}
+    for s in (1, 5, 10, 11):
+        r = cli(3, ["-n", 64, "-s", s, "--precision", "double", "--algorithm", "all-pairs", "--workload", "galaxy", "--print-state"])
+        outs[s] = r.stdout.split("Final state:")[1].split("Done simulation")[0]
+    assert outs[1] == outs[5] == outs[10] and outs[10] != outs[11]
+
+
+def test_csv_rows():
+    r = cli(3, ["-n", 1000, "-s", 5, "--precision", "double", "--algorithm", "all-pairs", "--csv-total"])
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "algorithm,dim,precision,nsteps,nbodies,total [s]"
+    # steps - warmup wraps as size_t, as printed by the reference
+    assert re.fullmatch(r"all-pairs,3,64,18446744073709551611,1000,\d+\.\d\d", lines[1])
+    r = cli(2, ["-n", 500, "-s", 3, "--algorithm", "all-pairs-collapsed", "--csv-detailed"])
+    assert re.fullmatch(r"all-pairs-collapsed,2,32,3,500,\d+\.\d\d,\d+\.\d\d,\d+\.\d\d", r.stdout.strip())  # no header in detailed mode
+    r = cli(3, ["-n", 500, "-s", 3, "--algorithm", "bvh", "--precision", "double", "--csv-detailed", "--print-info"])
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "algorithm,dim,precision,nsteps,nbodies,total [s],force [s],accel [s],bbox [s],sort [s],multipoles [s],force approx [s]"
+    assert sum(1 for l in lines if l.startswith("Total mass:  1.00000")) == 3
+    assert re.fullmatch(r"bvh,3,64,3,500(,\d+\.\d\d){7}", lines[-1])
+    r = cli(3, ["-n", 100, "--csv-total", "--print-state", "--algorithm", "bvh"])
+    assert r.returncode != 0  # abort(), as the reference (src/bvh.h:334-339)
+    r = cli(3, ["-n", 100, "--algorithm", "octree"])
+    assert r.returncode == 1 and "octree" in r.stderr
+
+
+def test_saved_frames_and_energy_vs_reference(oracle, golden_positions):
+    """--save all --csv-detailed writes steps+1 frames and energy pairs in the reference's binary formats."""
+    meta, data = golden_positions
+    ran = 0
+    for name, case in meta.items():
+        if name + "__energy" not in data.files or case["algorithm"] == "all-pairs-collapsed":
+            continue
+        dbl = case["precision"] == "double"
+        with tempfile.TemporaryDirectory() as d:
+            args = ["-n", case["n"], "-s", case["steps"], "--precision", case["precision"], "--algorithm", case["algorithm"],
+                    "--workload", case["workload"], "--save", "all", "--csv-detailed"]
+            if case["theta"] is not None:
+                args += ["--theta", case["theta"]]
+            r = cli(case["dim"], args, cwd=d)
+            assert r.returncode == 0, r.stderr
+            frames, hdr_steps = oracle.read_positions_bin(os.path.join(d, "positions.bin"))
+            en, _ = oracle.read_energy_bin(os.path.join(d, "energy.bin"))
+        ref, ref_en = data[name + "__frames"], data[name + "__energy"]
+        assert frames.shape == ref.shape and hdr_steps == case["steps"] and frames.dtype == ref.dtype
+        assert np.array_equal(frames[0], ref[0])
+        assert np.abs(frames - ref).max() <= (1e-11 if dbl else 2e-3) * np.abs(ref[0]).max(), name
+        assert en.shape == ref_en.shape
+        np.testing.assert_allclose(en, ref_en, rtol=1e-11 if dbl else 2e-3, err_msg=name)
+        ran += 1
+    assert ran >= 20
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_calc_energies_vs_oracle(nb, oracle, dtype, dim):
+    for wl, n in (("uniform", 1), ("uniform", 2), ("galaxy", 255), ("uniform", 256), ("galaxy", 257), ("uniform", 5000)):
+        ref = oracle.build_model(dtype, dim, wl, n)
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+        ke, pe = dev.calc_energies()
+        oke, ope = oracle.calc_energies(ref)
+        tol = 1e-12 if dtype == 1 else 2e-4  # float: the reference's sequential float sum carries ~1e-4 itself
+        assert abs(ke - oke) <= tol * max(abs(oke), 1e-30) and abs(pe - ope) <= tol * max(abs(ope), 1e-30), (wl, n, ke, oke, pe, ope)
+    s = nb.HostSystem(1, 3, 3)  # coincident distinct bodies keep the reference's m_i*m_j/eps term; self pairs are excluded
+    s.m[:] = [1, 2, 3]
+    s.c = 1.0
+    d = nb.DeviceSystem.from_host(s)
+    _, pe = d.calc_energies()
+    assert abs(pe + 0.5 * 2 * (1 * 2 + 1 * 3 + 2 * 3) / np.finfo(np.float64).eps) <= 1e-12 * abs(pe)

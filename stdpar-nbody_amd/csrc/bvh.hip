@@ -526,6 +526,34 @@ __device__ __forceinline__ void accumulate_monopole(T (&acc)[D], const T (&xs)[D
   pair_accumulate<T, D>(acc, xs, s);
 }
 
+// predicated forms (see pair_accumulate_if in common.hpp)
+template <typename T, int D>
+__device__ __forceinline__ void accumulate_leaf_pair_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& rc) {
+  src_rec<T, D> sa, sb;
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    sa.p[k] = rc.v[k];
+    sb.p[k] = rc.v[D + 1 + k];
+  }
+  sa.m = rc.v[D];
+  sb.m = rc.v[2 * D + 1];
+  pair_accumulate_if<T, D>(take, acc, xs, sa);
+  pair_accumulate_if<T, D>(take, acc, xs, sb);
+}
+
+template <typename T, int D>
+__device__ __forceinline__ void accumulate_monopole_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& nd) {
+  src_rec<T, D> s;
+#pragma unroll
+  for (int k = 0; k < D; ++k) s.p[k] = nd.v[k];
+  s.m = nd.v[D];
+  pair_accumulate_if<T, D>(take, acc, xs, s);
+}
+
+// The per-lane kernel is software-pipelined: a step's DECISION (opening test -> next node) is the serial chain,
+// the accepted term's arithmetic is not on it.  So each iteration decides, issues the load of the next record,
+// and only then accumulates the current record — ~27 issue slots with a ~170-cycle dependent chain that now run
+// under the next load's latency instead of in front of it (34.6 -> 22.8 ms at N=1e6, 1.82 -> 1.32 ms at N=1e5).
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
                                                        T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
@@ -543,39 +571,46 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
   const uint32_t leaf_level = nlevels;
   const uint32_t leaf_first = (1u << leaf_level) - 1u;
   uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
+  tree_rec<T> rec = node[0];
 
   while (covered < sz) {
-    if (level == leaf_level) {  // src/bvh.h:288-303
-      const uint32_t bidx  = tree_index - leaf_first;
-      const tree_rec<T> rc = node[uint64_t(nnodes) + (bidx >> 1)];
-      accumulate_leaf_pair<T, D>(acc, xs, rc);
+    const bool leaf = level == leaf_level;
+    // decision (src/bvh.h:288, :306); the test on a leaf record is computed but ignored
+    const bool approx = can_approximate<T, D>(xs, rec, theta2);
+    uint32_t n_index, n_level = level, n_cov = covered;
+    if (leaf || approx) {
+      n_cov = covered + (leaf ? 2u : (1u << (nlevels - level)));
+      if (leaf || ((tree_index - 1u) & 1u)) {  // leaf / right child -> parent + 1 (src/bvh.h:272-281, :115-120)
+        n_index = (level == 0) ? 1u : ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
+        n_level = level - 1u;
+      } else {
+        n_index = tree_index + 1u;
+      }
+    } else {  // descend to the left child (src/bvh.h:126-130,283-286)
+      const uint32_t f = (1u << level) - 1u;
+      n_index          = (tree_index - f) * 2u + f + (1u << level);
+      n_level          = level + 1u;
+    }
+    // next record, requested before the current one is accumulated
+    tree_rec<T> nrec = rec;
+    if (n_cov < sz) nrec = node[n_level == leaf_level ? uint64_t(nnodes) + ((n_index - leaf_first) >> 1) : uint64_t(n_index)];
+    if (leaf) {  // src/bvh.h:288-303
+      accumulate_leaf_pair<T, D>(acc, xs, rec);
       if (COUNT) {
-        c_body += (bidx != i) + uint32_t(bidx + 1 < sz && bidx + 1 != i);
+        c_body += (covered != i) + uint32_t(covered + 1 < sz && covered + 1 != i);
         ++c_leaf;
       }
-      covered += 2;
-      // force_ascend_right: parent + 1 (src/bvh.h:272-275, :115-120)
-      tree_index = ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
-      level -= 1;
     } else {
-      const tree_rec<T> nd = node[tree_index];
       if (COUNT) ++c_nodes;
-      if (can_approximate<T, D>(xs, nd, theta2)) {
-        accumulate_monopole<T, D>(acc, xs, nd);
+      if (approx) {
+        accumulate_monopole<T, D>(acc, xs, rec);
         if (COUNT) ++c_mono;
-        covered += 1u << (nlevels - level);
-        if ((tree_index - 1u) & 1u) {  // right child -> parent + 1 (src/bvh.h:277-281)
-          tree_index = (level == 0) ? 1u : ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
-          level -= 1;
-        } else {
-          tree_index += 1;
-        }
-      } else {  // descend to the left child (src/bvh.h:126-130,283-286)
-        const uint32_t f = (1u << level) - 1u;
-        tree_index       = (tree_index - f) * 2u + f + (1u << level);
-        level += 1;
       }
     }
+    rec        = nrec;
+    tree_index = n_index;
+    level      = n_level;
+    covered    = n_cov;
   }
 #pragma unroll
   for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
@@ -588,7 +623,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9, wave-cooperative form (default).
+// K9, wave-cooperative form.
 //
 // Every lane still performs exactly the reference's own sequence of node tests / leaf visits, in its own
 // order, with its own decisions (results and counters are bitwise those of bvh_force_kernel).  What
@@ -597,12 +632,14 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // lexicographic order, which is DFS pre-order.  The wave therefore sweeps the UNION of its 64 lanes' nodes
 // once, in key order: at each step the record is wave-uniform (one scalar load instead of 64 divergent
 // gathers), lanes whose key equals the current one take part, the others wait.  Lanes can no longer drift
-// apart.  Union per wave at config 4: ~7.5k node tests vs ~4.2k per lane.
-//
-// The walk is a serial chain (decision -> next record -> decision); its latency is hidden by the other waves
-// of the SIMD (8 resident).  Speculatively fetching both possible successors was measured and is WORSE
-// (26 vs 14 ms at config 4): scalar loads return out of order, so each step would wait for the not-taken
-// successor too, which is often a cold miss.
+// apart, which is what makes the per-lane walk slow at full occupancy.  Union per wave at config 4: ~7.5k
+// node tests vs ~4.2k per lane, so with few waves in flight (N < ~400k) the per-lane form is faster.
+// This form is bound by the CU's single scalar unit (~50 SALU instructions per step, 67 % busy at config 4).
+// Measured and rejected: fetching both possible successors speculatively (scalar loads return out of order,
+// so every step waits for the not-taken, often cold, one: 26 vs 14 ms); a wave-private LDS window over a
+// pre-order copy of the tree filled by LDS-DMA (15.6 ms: refills cost more than the misses they replace);
+// pipelining the next record's load ahead of the accumulation as in the per-lane kernel (18.7 ms: the SGPR
+// record copies it needs overload the scalar unit).
 // Packed key = covered << 5 | level, so this form needs nlevels <= 26.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D, bool COUNT>
@@ -635,44 +672,54 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   for (;;) {
     cur                  = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; pin it to an SGPR
     const uint32_t level = cur & 31u, cov = cur >> 5;
-    if (cov >= sz) break;  // every remaining key is >= cur: all lanes are finished
+    if (cov >= sz) {  // every remaining key is >= cur: all lanes are finished
+      if (valid) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+        if (COUNT) {
+          counters[uint64_t(i) * 4 + 0] = c_nodes;
+          counters[uint64_t(i) * 4 + 1] = c_leaf;
+          counters[uint64_t(i) * 4 + 2] = c_mono;
+          counters[uint64_t(i) * 4 + 3] = c_body;
+        }
+      }
+      return;
+    }
     const bool leaf      = level == leaf_level;
     const tree_rec<T> rc = node[rec_index(cur)];  // wave-uniform address: one scalar load
 
     // keys of the two possible successors
-    const uint32_t idx  = leaf ? 0u : ((1u << level) - 1u) + (cov >> (nlevels - level));
-    const uint32_t ncov = cov + (leaf ? 2u : (1u << (nlevels - level)));
+    const uint32_t span = leaf ? 2u : (1u << (nlevels - level));
+    const uint32_t ncov = cov + span;
     // leaf -> parent + 1 (level - 1); left child -> sibling (same level); right child -> parent + 1  (src/bvh.h:272-281)
-    const uint32_t nlev = (leaf || ((idx - 1u) & 1u)) ? level - 1u : level;
+    // (a node is a right child iff its position in the level, covered / span, is odd; the root counts as one)
+    const uint32_t nlev = (leaf || level == 0u || (cov & span)) ? level - 1u : level;
     const uint32_t ka   = (ncov >= sz) ? DONE : ((ncov << 5) | (nlev & 31u));
     const uint32_t kd   = cur + 1u;  // descend: same covered, level + 1  (src/bvh.h:283-286)
 
     const bool active = key == cur;
     bool any_reject   = false;
-    if (leaf) {  // src/bvh.h:288-303
-      if (active) {
-        accumulate_leaf_pair<T, D>(acc, xs, rc);
-        if (COUNT) {
-          c_body += (cov != i) + uint32_t(cov + 1 < sz && cov + 1 != i);
-          ++c_leaf;
-        }
-        key = ka;
+    if (leaf) {  // src/bvh.h:288-303 (cur is some lane's key, so at least one lane is active)
+      accumulate_leaf_pair_if<T, D>(active, acc, xs, rc);
+      if (COUNT && active) {
+        c_body += (cov != i) + uint32_t(cov + 1 < sz && cov + 1 != i);
+        ++c_leaf;
       }
+      key = active ? ka : key;
     } else {
       const bool approx = can_approximate<T, D>(xs, rc, theta2);
       const bool accept = active && approx;
       const bool reject = active && !approx;
       if (COUNT && active) ++c_nodes;
-      if (accept) {
-        accumulate_monopole<T, D>(acc, xs, rc);
-        if (COUNT) ++c_mono;
-        key = ka;
+      if (__ballot(accept) != 0ull) {  // wave-uniform branch, per-lane predication of the weight
+        accumulate_monopole_if<T, D>(accept, acc, xs, rc);
+        if (COUNT && accept) ++c_mono;
       }
-      if (reject) key = kd;
+      key        = accept ? ka : (reject ? kd : key);
       any_reject = __ballot(reject) != 0ull;
     }
     if (any_reject) {
-      cur = kd;  // the left child is the smallest key any lane can now hold
+      cur = kd;  // a lane opened the node: the left child is the smallest key any lane can now hold
     } else {
       // smallest key held by any lane: start from the finishing lanes' key, refine while some lane is behind it
       uint32_t cand   = ka;
@@ -682,16 +729,6 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
         behind = __ballot(key < cand);
       }
       cur = cand;
-    }
-  }
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
-    if (COUNT) {
-      counters[uint64_t(i) * 4 + 0] = c_nodes;
-      counters[uint64_t(i) * 4 + 1] = c_leaf;
-      counters[uint64_t(i) * 4 + 2] = c_mono;
-      counters[uint64_t(i) * 4 + 3] = c_body;
     }
   }
 }
@@ -788,7 +825,9 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th2 = th * th;  // src/bvh.h:252, in T
   const uint32_t blocks = (s->count + 63) / 64;
   auto* node = static_cast<const tree_rec<T>*>(t->node);
-  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26);
+  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain (crossover ~400k bodies
+  // on 256 CUs: 9.1 vs 9.5 ms at 500k, 6.2 vs 4.1 ms at 250k)
+  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= 400000u);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;

@@ -128,6 +128,24 @@ __device__ __forceinline__ void pair_accumulate(T (&acc)[D], const T (&xi)[D], c
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
 }
 
+// Same, for lanes selected by `take`; the others add w = 0, i.e. exactly nothing (d is finite).  Used by the
+// wave-cooperative traversal under a WAVE-UNIFORM branch: predicating the weight (2 v_cndmask) instead of the
+// control flow keeps the accumulators in place — with a divergent `if` hipcc copies all of them at both ends of
+// every loop iteration.
+template <typename T, int D>
+__device__ __forceinline__ void pair_accumulate_if(bool take, T (&acc)[D], const T (&xi)[D], const src_rec<T, D>& s) {
+  T d[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) d[k] = s.p[k] - xi[k];
+  T r2 = pair_math<T>::tiny;
+#pragma unroll
+  for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+  T w = pair_math<T>::weight(r2, s.m);
+  w   = take ? w : T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 }  // namespace nbody

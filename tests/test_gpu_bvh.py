@@ -17,10 +17,11 @@ def maxrel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def _phases(nb, oracle, dtype, dim, wl, n, theta, counts=True):
+def _phases(nb, oracle, dtype, dim, wl, n, theta, counts=True, traversal=0):
     ref = oracle.build_model(dtype, dim, wl, n)
     dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
     st, t = dev.state(), dev.bvh
+    t.set_traversal(traversal)
     t.enable_counters(counts)
     t.bounding_box(st, dev.stream)
     lo, hi = t.get_bounding_box(dev.stream)
@@ -55,7 +56,7 @@ def test_bvh_phases_bit_exact(nb, oracle, dtype, dim):
     for wl, n in (("uniform", 2), ("uniform", 3), ("uniform", 5), ("galaxy", 64), ("uniform", 257), ("galaxy", 1000),
                   ("uniform", 2049), ("galaxy", 10000)):
         for theta in (0.0, 0.5, 1.0):
-            _phases(nb, oracle, dtype, dim, wl, n, theta)
+            _phases(nb, oracle, dtype, dim, wl, n, theta, traversal=1 + (n % 2))  # both K9 forms get covered
 
 
 @pytest.mark.parametrize("dtype", [1, 0])

@@ -1,0 +1,19 @@
+"""Diagnostic: time K9 in its three scheduling forms at a given N (3D galaxy theta=0.5)."""
+import sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+from conftest import load_package
+nb = load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64
+dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+st, t = dev.state(), dev.bvh
+t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream); dev.sync()
+for mode in (1, 2):
+    t.set_traversal(mode)
+    t.compute_force(st, 0.5, dev.stream); dev.sync()
+    t0 = time.perf_counter()
+    reps = 5
+    for _ in range(reps):
+        t.compute_force(st, 0.5, dev.stream)
+    dev.sync()
+    print(f"n={n} dtype={dtype} traversal mode {mode}: {(time.perf_counter()-t0)/reps*1e3:.2f} ms", flush=True)

@@ -149,6 +149,17 @@ void* nbody_ctx_stream(nbody_ctx* ctx);
 /* Blocks until all work queued on `stream` has completed (so wall-clock phase timers are honest). */
 int  nbody_stream_sync(void* stream);
 
+/* ---- step graphs ----------------------------------------------------------------------------------------
+ * A simulation step is a fixed sequence of phase calls (5 launches for all-pairs, ~40 for bvh).  Between
+ * nbody_graph_begin and nbody_graph_end the phase calls made on `stream` are recorded instead of executed
+ * (HIP stream capture); nbody_graph_launch replays the whole step with one submission.  Only the asynchronous
+ * phase calls may be recorded (no upload/download/read/get/sync/calc_energies inside a capture). */
+typedef struct nbody_graph nbody_graph;
+int  nbody_graph_begin(void* stream);
+int  nbody_graph_end(void* stream, nbody_graph** out);
+int  nbody_graph_launch(nbody_graph* g, void* stream);
+void nbody_graph_destroy(nbody_graph* g);
+
 #ifdef __cplusplus
 }
 #endif

@@ -47,6 +47,7 @@ ABI_SYMBOLS = [
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
     "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
+    "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
 ]
 
 _lib = None
@@ -297,6 +298,32 @@ def _load_sharded():
 
 
 parallel = _load_sharded()
+
+
+class StepGraph:
+    """Records the phase calls of one step on the device's stream (HIP stream capture) and replays them."""
+
+    def __init__(self, dev, record):
+        self.dev, self.h = dev, C.c_void_p()
+        _check(lib().nbody_graph_begin(C.c_void_p(dev.stream)))
+        try:
+            record()
+        finally:
+            _check(lib().nbody_graph_end(C.c_void_p(dev.stream), C.byref(self.h)))
+
+    def launch(self):
+        _check(lib().nbody_graph_launch(self.h, C.c_void_p(self.dev.stream)))
+
+    def close(self):
+        if self.h:
+            lib().nbody_graph_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def executed_steps(steps, csv_detailed, warmup=10):

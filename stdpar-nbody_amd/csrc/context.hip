@@ -145,3 +145,46 @@ extern "C" int nbody_stream_sync(void* stream) {
   NB_HIP(hipStreamSynchronize(as_stream(stream)));
   return NBODY_OK;
 }
+
+// ---- step graphs ---------------------------------------------------------------------------------------------
+struct nbody_graph {
+  hipGraph_t graph    = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int nbody_graph_begin(void* stream) {
+  NB_ARG(stream != nullptr, "graph capture needs an explicit (non-default) stream");
+  NB_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
+  return NBODY_OK;
+}
+
+extern "C" int nbody_graph_end(void* stream, nbody_graph** out) {
+  NB_ARG(out != nullptr, "out is NULL");
+  *out = nullptr;
+  hipGraph_t graph = nullptr;
+  NB_HIP(hipStreamEndCapture(as_stream(stream), &graph));
+  hipGraphExec_t exec = nullptr;
+  hipError_t e        = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    return hip_fail(e, "hipGraphInstantiate", __FILE__, __LINE__);
+  }
+  auto* g  = new nbody_graph;
+  g->graph = graph;
+  g->exec  = exec;
+  *out     = g;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_graph_launch(nbody_graph* g, void* stream) {
+  NB_ARG(g != nullptr && g->exec != nullptr, "graph is NULL");
+  NB_HIP(hipGraphLaunch(g->exec, as_stream(stream)));
+  return NBODY_OK;
+}
+
+extern "C" void nbody_graph_destroy(nbody_graph* g) {
+  if (!g) return;
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
+}

@@ -64,6 +64,17 @@ class Device {
     return {ke, pe};
   }
 
+  // Record the phase calls issued by `step` once and return a replayable graph of them (one submission per step).
+  template <typename F>
+  nbody_graph* record(F&& step) {
+    nbody_graph* g = nullptr;
+    backend_check(nbody_graph_begin(stream()), "nbody_graph_begin");
+    step();
+    backend_check(nbody_graph_end(stream(), &g), "nbody_graph_end");
+    return g;
+  }
+  void replay(nbody_graph* g) { backend_check(nbody_graph_launch(g, stream()), "nbody_graph_launch"); }
+
   void bvh_alloc() {
     if (!tree_) backend_check(nbody_bvh_create(&tree_, dtype, D, host_.n), "nbody_bvh_create");
   }

@@ -1,10 +1,15 @@
-"""Diagnostic: time K1 (3D double all-pairs, galaxy) over (split, targets_per_thread) configs, full system and 1/8 shard."""
+"""Diagnostic: time K1 over (split, targets_per_thread) configs, full system and 1/8 shard.
+usage: tune_all_pairs.py [n] [double|float] [dim]"""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 from conftest import load_package
 nb = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-hs = nb.build_model(nb.F64, 3, "galaxy", n)
+dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64
+dim = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+peak = 157.3 if dtype == nb.F32 else 78.6
+flop = 20.0 if dim == 3 else 14.0
+hs = nb.build_model(dtype, dim, "galaxy", n)
 dev = nb.DeviceSystem.from_host(hs)
 for (label, first, count) in (("full", 0, n), ("1/8 shard", 0, n // 8)):
     for js in (1, 2, 4):
@@ -12,10 +17,10 @@ for (label, first, count) in (("full", 0, n), ("1/8 shard", 0, n // 8)):
             nb.configure_all_pairs(js, r)
             dev.all_pairs_force(first, count); dev.sync()
             t0 = time.perf_counter()
-            reps = 2 if count == n else 4
+            reps = 3
             for _ in range(reps):
                 dev.all_pairs_force(first, count)
             dev.sync()
             t = (time.perf_counter() - t0) / reps
-            tf = 20.0 * count * (n - 1) / t / 1e12
-            print(f"n={n} {label:10s} split={js} tpt={r}: {t*1e3:9.2f} ms  {tf:6.2f} TFLOP/s ({100*tf/78.6:5.1f}% of FP64 vector peak)", flush=True)
+            tf = flop * count * (n - 1) / t / 1e12
+            print(f"n={n} dim={dim} dtype={dtype} {label:10s} split={js} tpt={r}: {t*1e3:9.3f} ms  {tf:6.2f} TFLOP/s ({100*tf/peak:5.1f}% of vector peak)", flush=True)

@@ -136,3 +136,54 @@ def test_step_graph_replay_equals_direct_calls(nb):
         for k in ("m", "x", "v", "a", "ao"):
             assert np.array_equal(getattr(a, k), getattr(b, k)), (algo, k)
         g.close()
+
+
+def test_workload_load_bin(nb, oracle):
+    """--workload load f.bin: u32 n, u32 dim, f32 dt, f32 G, then n x (m, pos[D], vel[D]) as f32 (src/saving.h:25-68)."""
+    import struct
+    rng = np.random.default_rng(9)
+    n, dim = 200, 3
+    body = rng.standard_normal((n, 1 + 2 * dim)).astype(np.float32)
+    body[:, 0] = np.abs(body[:, 0]) + 0.1
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "sys.bin")
+        with open(path, "wb") as f:
+            f.write(struct.pack("<IIff", n, dim, 0.05, 2.0))
+            f.write(body.tobytes())
+        r = cli(3, ["--workload", "load", path, "--precision", "double", "--algorithm", "all-pairs", "-s", 3, "--csv-detailed", "--save", "pos"], cwd=d)
+        assert r.returncode == 0, r.stderr
+        frames, _ = oracle.read_positions_bin(os.path.join(d, "positions.bin"))
+        r2 = cli(2, ["--workload", "load", path])
+        assert r2.returncode != 0 and "compiled with D=2" in r2.stderr  # uncaught std::runtime_error, as the reference
+    s = oracle.State(oracle.F64, 3, n)
+    s.m[:], s.x[:], s.v[:] = body[:, 0], body[:, 1:4], body[:, 4:7]
+    s.dt, s.c = float(np.float32(0.05)), 2.0
+    ref = [s.x.copy()]
+    oracle.run(s, "all-pairs", 3, frames=ref)
+    assert frames.shape == (4, n, 3) and np.array_equal(frames[0], ref[0])
+    assert np.abs(frames - np.array(ref)).max() <= 1e-11 * np.abs(ref[0]).max()
+
+
+def test_call_sequence_and_shard_errors(nb):
+    """Error behaviour of the ABI on a live device: state errors, empty shards, whole-system-only phases."""
+    import ctypes as C
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "uniform", 100))
+    t, st = dev.bvh, dev.state()
+    with pytest.raises(nb.NbodyError, match="before nbody_bvh_bounding_box"):
+        t.hilbert_sort(st, dev.stream)
+    with pytest.raises(nb.NbodyError, match="before nbody_bvh_build_tree"):
+        t.compute_force(st, 0.5, dev.stream)
+    t.bounding_box(st, dev.stream)
+    with pytest.raises(nb.NbodyError, match="whole system"):
+        t.hilbert_sort(dev.state(10, 20), dev.stream)
+    with pytest.raises(nb.NbodyError, match="single-GPU"):
+        s2 = dev.state(10, 20)
+        nb._check(nb.lib().nbody_all_pairs_collapsed_force(C.byref(s2), C.c_void_p(dev.stream)))
+    before = dev.download().a.copy()
+    dev.all_pairs_force(50, 0)  # empty shard: nothing launched, nothing written
+    dev.accelerate_step(50, 0)
+    assert np.array_equal(dev.download().a, before)
+    with pytest.raises(nb.NbodyError, match="exceeds"):
+        dev.all_pairs_force(90, 20)
+    with pytest.raises(nb.NbodyError):
+        nb.Bvh(1, 3, 1)  # the reference's tree needs at least one body pair

@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1 << 20, help="bodies (default 2^20, the BASELINE.json metric config)")
+    ap.add_argument("--bodies", dest="n", type=int, default=1 << 20,
+                    help="bodies (default 2^20, the BASELINE.json metric config); `--n` would collide with torchrun option prefixes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -106,8 +107,11 @@ def main():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # NBODY_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather, max-reduce) even with one rank
+    use_dist = world > 1 or os.environ.get("NBODY_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -117,14 +121,14 @@ def main():
     # synthetic galaxy init with the product's host generator (host/models.hpp == src/models.h:112-136)
     hs = nb.build_model(nb.F64, 3, "galaxy", args.n)
     n = hs.n
-    sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev)
+    sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev, force_exchange=use_dist)
 
     def step():
         sim.step()
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -133,11 +137,11 @@ def main():
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         sim.step(force_events=(e0, e1))
         force_events.append((e0, e1))
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -177,7 +181,7 @@ def main():
             except Exception as ex:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "body-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

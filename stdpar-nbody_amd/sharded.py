@@ -41,7 +41,7 @@ class HipOps:
 class ShardedAllPairs:
     """run_all_pairs' step (force, then accelerate_step; src/all_pairs.h:86-91) over a shard of targets."""
 
-    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None):
+    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None, force_exchange=False):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -66,7 +66,8 @@ class ShardedAllPairs:
         self.ao = to(hs.ao[self.first:end])
         self.dt, self.c = float(hs.dt), float(hs.c)
         self.equal = hs.n % world == 0
-        self.send = torch.empty_like(self.x[self.first:end]) if world > 1 and self.equal else None
+        self.exchange = world > 1 or force_exchange  # force_exchange: run the collective even with one rank (smoke test)
+        self.send = torch.empty_like(self.x[self.first:end]) if self.exchange and self.equal else None
 
     def state(self):
         if self._state_cls is None:  # test ops work on the tensors directly
@@ -86,7 +87,7 @@ class ShardedAllPairs:
 
     def exchange_positions(self):
         """The one collective of the path: all ranks end up with every rank's updated position shard."""
-        if self.world == 1:
+        if not self.exchange:
             return
         end = self.first + self.count
         if self.equal:

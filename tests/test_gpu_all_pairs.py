@@ -255,3 +255,38 @@ def test_config3_collapsed_3d_float_262144(nb, oracle):
     """BASELINE config[2]: the reference computes nothing here (pair count wraps to 0); parity is pinned to
     all-pairs on a target sample."""
     _sample_check(nb, oracle, 0, 3, "uniform", 262144, "all_pairs_collapsed_force", nsample=64, tol=1e-4)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_pair_math_adversarial_separations(nb, oracle, dtype):
+    """Separations from far below eps^(1/3) (where the reference's `+ eps` dominates the denominator) up to 1e6, exact
+    coincidences, zero masses and 12 decades of mass ratio: per-target error against the oracle stays at rounding level."""
+    rng = np.random.default_rng(17)
+    t = np.float64 if dtype == 1 else np.float32
+    n = 3000
+    hs = nb.HostSystem(dtype, 3, n)
+    centers = rng.standard_normal((30, 3)) * 100.0
+    scale = 10.0 ** rng.uniform(-13 if dtype == 1 else -6, 3, size=n)          # cluster radii over many decades
+    x = centers[rng.integers(0, 30, n)] + rng.standard_normal((n, 3)) * scale[:, None]
+    x[100:110] = x[90:100]                                                      # exact coincidences
+    x[200] = 1e6
+    hs.x[:] = x.astype(t)
+    hs.m[:] = (10.0 ** rng.uniform(-6, 6, n)).astype(t)
+    hs.m[300:310] = 0
+    hs.c, hs.dt = 1.0, 0.1
+    ref = oracle.State(dtype, 3, n)
+    ref.m[:], ref.x[:], ref.c = hs.m, hs.x, 1.0
+    dev = nb.DeviceSystem.from_host(hs)
+    oracle.all_pairs_force(ref)
+    for split in (1, 4):
+        nb.configure_all_pairs(split, 1)
+        dev.all_pairs_force()
+        a = dev.download().a.astype(np.float64)
+        assert np.all(np.isfinite(a))
+        # per target: error relative to the sum of the magnitudes of its terms ~ |a| scale of the dominant term
+        err = np.abs(a - ref.a).max(axis=1)
+        mag = np.abs(ref.a).max(axis=1) + 1e-300
+        tol = 2e-13 if dtype == 1 else 1e-4
+        bad = np.where(err > tol * np.maximum(mag, np.median(mag)))[0]
+        assert bad.size == 0, (split, bad[:5], err[bad[:5]], mag[bad[:5]])
+    nb.configure_all_pairs(0, 0)

@@ -638,8 +638,8 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // Measured and rejected: fetching both possible successors speculatively (scalar loads return out of order,
 // so every step waits for the not-taken, often cold, one: 26 vs 14 ms); a wave-private LDS window over a
 // pre-order copy of the tree filled by LDS-DMA (15.6 ms: refills cost more than the misses they replace);
-// pipelining the next record's load ahead of the accumulation as in the per-lane kernel (18.7 ms: the SGPR
-// record copies it needs overload the scalar unit).
+// pipelining the next record's load ahead of the accumulation as in the per-lane kernel (18.7 ms with SGPR record
+// copies, which overload the scalar unit; 15.6 ms with ping-pong record registers and no copies — still no gain).
 // Packed key = covered << 5 | level, so this form needs nlevels <= 26.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int D, bool COUNT>

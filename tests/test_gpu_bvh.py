@@ -156,3 +156,21 @@ def test_config4_n1e6_galaxy_theta05_vs_oracle(nb, oracle):
     """BASELINE config[3]: bvh 3D double N=1e6 galaxy theta=0.5 — the whole force phase against the oracle:
     bit-exact traversal counters for every body, force within tolerance."""
     _phases(nb, oracle, 1, 3, "galaxy", 1000000, 0.5)
+
+
+def test_traversal_shard_windows_bitwise(nb):
+    """K9 over a window of targets (first/count) equals the same rows of the full traversal, in both forms."""
+    n = 9000
+    for mode in (1, 2):
+        dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+        t = dev.bvh
+        t.set_traversal(mode)
+        dev.bvh_force(0.5)
+        full = dev.download().a.copy()
+        hs = dev.download()
+        hs.a[:] = 0
+        dev.upload(hs)
+        for f, c in ((0, 1000), (1000, 4001), (5001, 3999)):
+            t.compute_force(dev.state(f, c), 0.5, dev.stream)
+        assert np.array_equal(dev.download().a, full), mode
+        dev.close()

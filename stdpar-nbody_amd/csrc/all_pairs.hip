@@ -13,9 +13,9 @@
 //
 // K2 (replaces src/all_pairs.h:29-50, intended semantics).  Lanes run along the SOURCE axis (one
 // ordered pair per lane and step), each wave owns 64 targets whose positions it broadcasts with
-// v_readlane; the per-target partial over 64*KJ sources is reduced across the wavefront with
-// __shfl_xor, lane t keeps target t's sum, and after the tile each wave issues D coalesced atomic
-// adds.  grid.y splits the source range so small N still fills the chip.
+// v_readlane; the per-target partial over 64*KJ sources is reduced across the wavefront with DPP
+// cross-lane adds (the __shfl family compiles to ds_bpermute here), lane t keeps target t's sum, and
+// after the tile each wave issues D coalesced atomic adds.  grid.y splits the source range so small N still fills the chip.
 //
 // K3 (replaces src/system.h:52-60).  Pure HBM stream (7*D*sizeof(T) bytes/body), flat elementwise
 // over count*D scalars, FP contraction off so it is bit-identical to the reference's x86 -O2 build.
@@ -180,7 +180,8 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-// sources per LDS tile: 16 per lane in f32, 8 per lane in f64 (64 VGPRs of source registers either way)
+// sources per LDS tile: 16 per lane in f32, 8 per lane in f64 (64 VGPRs of source registers either way; 8 per lane in
+// f32 was measured slower, 34 vs 27 ms at config 3: the per-target broadcast + reduction is amortised over fewer pairs)
 template <typename T>
 constexpr int kColTileJ = sizeof(T) == 4 ? 1024 : 512;
 
@@ -191,11 +192,40 @@ __global__ __launch_bounds__(kBlock) void collapsed_reset_kernel(T* __restrict__
   if (e < n) a[e] = a[e] - ao[e];
 }
 
+// Wavefront sum over 64 lanes with DPP cross-lane adds (VALU data path; __shfl_xor compiles to ds_bpermute_b32,
+// which goes through the LDS crossbar at ~21 cycles each when every SIMD does it).  Quad swaps and row mirrors give
+// every lane of a 16-lane row the row sum; row_bcast:15 / row_bcast:31 (GFX9 DPP, present on gfx950) chain the four
+// rows so that lane 63 holds the total, which is returned wave-uniform through v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_i32(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);  // disabled/invalid lanes read 0
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __builtin_bit_cast(float, dpp_i32<CTRL, ROW_MASK>(__builtin_bit_cast(int, v)));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_get(double v) {
+  const long long b = __builtin_bit_cast(long long, v);
+  const int lo = dpp_i32<CTRL, ROW_MASK>(int(b)), hi = dpp_i32<CTRL, ROW_MASK>(int(b >> 32));
+  return __builtin_bit_cast(double, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+}
+
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  v += dpp_get<0xB1>(v);        // quad_perm:[1,0,3,2]
+  v += dpp_get<0x4E>(v);        // quad_perm:[2,3,0,1]
+  v += dpp_get<0x141>(v);       // row_half_mirror
+  v += dpp_get<0x140>(v);       // row_mirror       -> every lane of a row holds its row's sum
+  v += dpp_get<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+  } else {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_readlane(int(b), 63), hi = __builtin_amdgcn_readlane(int(b >> 32), 63);
+    return __builtin_bit_cast(T, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
+  }
 }
 
 template <typename T>

@@ -526,6 +526,15 @@ __device__ __forceinline__ void accumulate_monopole(T (&acc)[D], const T (&xs)[D
   pair_accumulate<T, D>(acc, xs, s);
 }
 
+// XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), while
+// Hilbert-neighbour waves walk nearly the same near-field records.  Remapping the block id so that each XCD works
+// on one contiguous range of bodies lets neighbours share their XCD's 4 MiB L2.  Bijective for any grid size
+// (MI355X_MICROARCH: placement is a speed matter only, never correctness).
+__device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nblocks) {
+  const uint32_t q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, slot = b / 8u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}
+
 // predicated forms (see pair_accumulate_if in common.hpp)
 template <typename T, int D>
 __device__ __forceinline__ void accumulate_leaf_pair_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& rc) {
@@ -558,7 +567,7 @@ template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
                                                        T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
                                                        uint32_t nlevels, uint32_t nnodes, uint32_t* __restrict__ counters) {
-  const uint32_t local = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (local >= count) return;
   const uint32_t i = first + local;
   T xs[D], acc[D];
@@ -648,7 +657,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
                                                             uint32_t count, T theta2, uint32_t nlevels, uint32_t nnodes,
                                                             uint32_t* __restrict__ counters) {
   constexpr uint32_t DONE = 0xffffffffu;
-  const uint32_t local = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid     = local < count;
   const uint32_t i     = first + (valid ? local : 0u);
   T xs[D], acc[D];

@@ -7,10 +7,10 @@
 //   idx[2]    u32[n] x2         ping-pong payload (original body index); the final one is the permutation
 //   hist      u32[256*(nblk+1)] per-(digit, block) counts -> exclusive offsets per digit row, + 256 digit totals
 //   tmp       T[n*(4D+1)]       gather scratch for the in-place permutation of m,x,v,a,ao
-//   node      rec[nnodes+nleafs/2]  one 8-scalar record per internal node (COM, mass, width, width^2) followed by
-//                               one per leaf PAIR (both bodies' position+mass), so the traversal touches
-//                               exactly one aligned record per step (the reference keeps m/bw/b in three
-//                               arrays and reads bodies from x and m, src/bvh.h:103-106,294-295).
+//   node      rec[nnodes+nleafs]  one 8-scalar record per internal node (COM, mass, width, width^2) followed by one
+//                               per body slot (position, mass), so the traversal touches exactly one aligned
+//                               record per step (the reference keeps m/bw/b in three arrays and reads bodies
+//                               from x and m, src/bvh.h:103-106,294-295).
 //   box       T[nnodes*2D]      node AABBs, only used by the build
 // Everything integer (keys, sort, permutation, traversal decisions, node visit counts) is bit-exact
 // against the oracle; tree COMs/widths are bit-exact too (FP contraction is off in the build and in
@@ -25,9 +25,14 @@ namespace nbody {
 constexpr int kB = 256;
 
 // One 8-scalar record (32 B f32 / 64 B f64) per tree entry, so every traversal step is ONE aligned load:
-//   internal node i (i < nnodes):   v[0..D-1] centre of mass, v[D] mass, v[D+1] width, v[D+2] width^2
-//   leaf pair k (index nnodes + k): v[0..D-1] x[2k], v[D] m[2k], v[D+1..2D] x[2k+1], v[2D+1] m[2k+1]
-//                                   (an absent body 2k+1 >= N is stored as zeros: mass 0 contributes exactly 0)
+//   internal node i (level l < nlevels, index (2^l - 1) + k): v[0..D-1] centre of mass, v[D] mass, v[D+1] width,
+//                                                               v[D+2] width^2
+//   body b (level nlevels, index (2^nlevels - 1) + b):          v[0..D-1] x[b], v[D] m[b]; absent bodies b >= N
+//                                                               are zero records (mass 0 contributes exactly 0)
+// i.e. the implicit complete binary tree of the reference (src/bvh.h:108-138) continued by one level: the bodies.
+// A body entry is "always accepted", and the reference's ascend rules (left child -> sibling, right child ->
+// parent + 1) then visit a leaf pair exactly as src/bvh.h:288-303 does — body 2k, body 2k+1, then the
+// leaf-parent's right neighbour — so the traversal kernels need no separate leaf path.
 template <typename T>
 struct alignas(sizeof(T) * 8) tree_rec {
   T v[8];
@@ -396,9 +401,9 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
   const uint32_t i  = first + li;
   const uint64_t bl = uint64_t(li) * 2, br = bl + 1;
   const T tol = T(double(sizeof(T) == 4 ? double(FLT_EPSILON) : DBL_EPSILON) * 10.);
-  tree_rec<T> r, pair;
+  tree_rec<T> r, ba, bb;  // this node and its two body entries
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r.v[k] = pair.v[k] = T(0);
+  for (int k = 0; k < 8; ++k) r.v[k] = ba.v[k] = bb.v[k] = T(0);
   T* b = box + uint64_t(i) * 2 * D;
   if (bl >= nbodies) {  // dead node (src/bvh.h:185-188): mass 0; box/width are don't-care in the reference, 0 here
 #pragma unroll
@@ -406,14 +411,14 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
   } else if (br >= nbodies) {  // single body (src/bvh.h:190-194)
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      T p       = x[bl * D + k];
-      r.v[k]    = p;
-      pair.v[k] = p;
-      b[k]      = p - tol;
-      b[D + k]  = p + tol;
+      T p      = x[bl * D + k];
+      r.v[k]   = p;
+      ba.v[k]  = p;
+      b[k]     = p - tol;
+      b[D + k] = p + tol;
     }
     r.v[D]     = m[bl];
-    pair.v[D]  = r.v[D];
+    ba.v[D]    = r.v[D];
     r.v[D + 1] = node_width<T, D>(b);
   } else {  // two bodies (src/bvh.h:195-205)
     const T ml = m[bl], mr = m[br];
@@ -421,21 +426,22 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
 #pragma unroll
     for (int k = 0; k < D; ++k) {
       T p0 = x[bl * D + k], p1 = x[br * D + k];
-      T com             = ml * p0 + mr * p1;
-      r.v[k]            = com / mass;
-      pair.v[k]         = p0;
-      pair.v[D + 1 + k] = p1;
-      b[k]              = fmin_(p0, p1) - tol;
-      b[D + k]          = fmax_(p0, p1) + tol;
+      T com    = ml * p0 + mr * p1;
+      r.v[k]   = com / mass;
+      ba.v[k]  = p0;
+      bb.v[k]  = p1;
+      b[k]     = fmin_(p0, p1) - tol;
+      b[D + k] = fmax_(p0, p1) + tol;
     }
-    r.v[D]            = mass;
-    pair.v[D]         = ml;
-    pair.v[2 * D + 1] = mr;
-    r.v[D + 1]        = node_width<T, D>(b);
+    r.v[D]     = mass;
+    ba.v[D]    = ml;
+    bb.v[D]    = mr;
+    r.v[D + 1] = node_width<T, D>(b);
   }
-  r.v[D + 2]                   = r.v[D + 1] * r.v[D + 1];  // the product the opening test needs, rounded once
-  node[i]                      = r;
-  node[uint64_t(nnodes) + li] = pair;
+  r.v[D + 2]                          = r.v[D + 1] * r.v[D + 1];  // the product the opening test needs, rounded once
+  node[i]                             = r;
+  node[uint64_t(nnodes) + 2 * li]     = ba;  // body level continues the level-order numbering: nnodes = 2^nlevels - 1
+  node[uint64_t(nnodes) + 2 * li + 1] = bb;
 }
 
 // Levels [l_hi ... l_lo] (descending), one launch.  Levels with more than one block's worth of nodes
@@ -487,24 +493,8 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9 traversal  (src/bvh.h:246-324), per-lane form: the reference's loop as is, one independent stackless
-// walk per lane.  Kept as the n > 2^26 fallback and as the cross-check of the wave-cooperative form.
-// Its weakness on a GPU: lanes drift apart in the tree, so node loads become fully divergent.
+// K9 traversal  (src/bvh.h:246-324)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__device__ __forceinline__ void accumulate_leaf_pair(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& rc) {
-  src_rec<T, D> sa, sb;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    sa.p[k] = rc.v[k];
-    sb.p[k] = rc.v[D + 1 + k];
-  }
-  sa.m = rc.v[D];
-  sb.m = rc.v[2 * D + 1];
-  pair_accumulate<T, D>(acc, xs, sa);  // the self pair and an absent second body add exactly 0
-  pair_accumulate<T, D>(acc, xs, sb);
-}
-
 template <typename T, int D>
 __device__ __forceinline__ bool can_approximate(const T (&xs)[D], const tree_rec<T>& nd, T theta2) {
 #pragma clang fp contract(off)
@@ -517,13 +507,22 @@ __device__ __forceinline__ bool can_approximate(const T (&xs)[D], const tree_rec
   return nd.v[D + 2] < theta2 * d2;  // bw*bw < theta^2 * dist2, src/bvh.h:246-248
 }
 
+// acc += m * (p - xs) / dist3 for a node's monopole (src/bvh.h:308) or a body (src/bvh.h:297): same expression
 template <typename T, int D>
-__device__ __forceinline__ void accumulate_monopole(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& nd) {
+__device__ __forceinline__ void accumulate_entry(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& e) {
   src_rec<T, D> s;
 #pragma unroll
-  for (int k = 0; k < D; ++k) s.p[k] = nd.v[k];
-  s.m = nd.v[D];
+  for (int k = 0; k < D; ++k) s.p[k] = e.v[k];
+  s.m = e.v[D];
   pair_accumulate<T, D>(acc, xs, s);
+}
+template <typename T, int D>
+__device__ __forceinline__ void accumulate_entry_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& e) {
+  src_rec<T, D> s;
+#pragma unroll
+  for (int k = 0; k < D; ++k) s.p[k] = e.v[k];
+  s.m = e.v[D];
+  pair_accumulate_if<T, D>(take, acc, xs, s);
 }
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), while
@@ -535,38 +534,15 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nb
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
 }
 
-// predicated forms (see pair_accumulate_if in common.hpp)
-template <typename T, int D>
-__device__ __forceinline__ void accumulate_leaf_pair_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& rc) {
-  src_rec<T, D> sa, sb;
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    sa.p[k] = rc.v[k];
-    sb.p[k] = rc.v[D + 1 + k];
-  }
-  sa.m = rc.v[D];
-  sb.m = rc.v[2 * D + 1];
-  pair_accumulate_if<T, D>(take, acc, xs, sa);
-  pair_accumulate_if<T, D>(take, acc, xs, sb);
-}
-
-template <typename T, int D>
-__device__ __forceinline__ void accumulate_monopole_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& nd) {
-  src_rec<T, D> s;
-#pragma unroll
-  for (int k = 0; k < D; ++k) s.p[k] = nd.v[k];
-  s.m = nd.v[D];
-  pair_accumulate_if<T, D>(take, acc, xs, s);
-}
-
-// The per-lane kernel is software-pipelined: a step's DECISION (opening test -> next node) is the serial chain,
-// the accepted term's arithmetic is not on it.  So each iteration decides, issues the load of the next record,
-// and only then accumulates the current record — ~27 issue slots with a ~170-cycle dependent chain that now run
-// under the next load's latency instead of in front of it (34.6 -> 22.8 ms at N=1e6, 1.82 -> 1.32 ms at N=1e5).
+// Per-lane form: the reference's loop, one independent stackless walk per lane.  With bodies as tree entries every
+// iteration is the same short program — fetch, (test), accumulate if accepted, move — so a lane standing on a body
+// no longer makes the whole wave run a separate two-body path.  Software-pipelined: a step's DECISION (opening
+// test -> next entry) is the serial chain, the accepted term's arithmetic is not, so each iteration decides,
+// requests the next record, and only then accumulates the current one.
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
                                                        T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
-                                                       uint32_t nlevels, uint32_t nnodes, uint32_t* __restrict__ counters) {
+                                                       uint32_t nlevels, uint32_t* __restrict__ counters) {
   const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (local >= count) return;
   const uint32_t i = first + local;
@@ -577,22 +553,20 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     acc[k] = T(0);
   }
   uint32_t tree_index = 0, level = 0, covered = 0;
-  const uint32_t leaf_level = nlevels;
-  const uint32_t leaf_first = (1u << leaf_level) - 1u;
   uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
   tree_rec<T> rec = node[0];
 
   while (covered < sz) {
-    const bool leaf = level == leaf_level;
-    // decision (src/bvh.h:288, :306); the test on a leaf record is computed but ignored
-    const bool approx = can_approximate<T, D>(xs, rec, theta2);
+    const bool body = level == nlevels;
+    // decision: a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
+    const bool take = body || can_approximate<T, D>(xs, rec, theta2);
     uint32_t n_index, n_level = level, n_cov = covered;
-    if (leaf || approx) {
-      n_cov = covered + (leaf ? 2u : (1u << (nlevels - level)));
-      if (leaf || ((tree_index - 1u) & 1u)) {  // leaf / right child -> parent + 1 (src/bvh.h:272-281, :115-120)
+    if (take) {
+      n_cov = covered + (1u << (nlevels - level));
+      if ((tree_index - 1u) & 1u) {  // right child -> parent + 1 (src/bvh.h:272-281, :115-120); the root counts as one
         n_index = (level == 0) ? 1u : ((1u << (level - 1)) - 1u) + (tree_index - ((1u << level) - 1u)) / 2u + 1u;
         n_level = level - 1u;
-      } else {
+      } else {  // left child -> sibling
         n_index = tree_index + 1u;
       }
     } else {  // descend to the left child (src/bvh.h:126-130,283-286)
@@ -602,20 +576,17 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     }
     // next record, requested before the current one is accumulated
     tree_rec<T> nrec = rec;
-    if (n_cov < sz) nrec = node[n_level == leaf_level ? uint64_t(nnodes) + ((n_index - leaf_first) >> 1) : uint64_t(n_index)];
-    if (leaf) {  // src/bvh.h:288-303
-      accumulate_leaf_pair<T, D>(acc, xs, rec);
-      if (COUNT) {
-        c_body += (covered != i) + uint32_t(covered + 1 < sz && covered + 1 != i);
-        ++c_leaf;
-      }
-    } else {
-      if (COUNT) ++c_nodes;
-      if (approx) {
-        accumulate_monopole<T, D>(acc, xs, rec);
-        if (COUNT) ++c_mono;
+    if (n_cov < sz) nrec = node[n_index];
+    if (COUNT) {
+      if (body) {
+        c_body += (covered != i);
+        c_leaf += !(covered & 1u);  // one leaf visit per body pair, counted at its first body
+      } else {
+        ++c_nodes;
+        c_mono += take;
       }
     }
+    if (take) accumulate_entry<T, D>(acc, xs, rec);  // the self pair adds exactly 0
     rec        = nrec;
     tree_index = n_index;
     level      = n_level;
@@ -634,16 +605,15 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // ------------------------------------------------------------------------------------------------
 // K9, wave-cooperative form.
 //
-// Every lane still performs exactly the reference's own sequence of node tests / leaf visits, in its own
-// order, with its own decisions (results and counters are bitwise those of bvh_force_kernel).  What
-// changes is WHEN: a lane's state is the key (covered, level) of the node it must visit next — `covered`
-// = index of the node's first leaf — and along any lane's walk that key only grows in (covered, level)
-// lexicographic order, which is DFS pre-order.  The wave therefore sweeps the UNION of its 64 lanes' nodes
-// once, in key order: at each step the record is wave-uniform (one scalar load instead of 64 divergent
-// gathers), lanes whose key equals the current one take part, the others wait.  Lanes can no longer drift
-// apart, which is what makes the per-lane walk slow at full occupancy.  Union per wave at config 4: ~7.5k
-// node tests vs ~4.2k per lane, so with few waves in flight (N < ~400k) the per-lane form is faster.
-// This form is bound by the CU's single scalar unit (~50 SALU instructions per step, 67 % busy at config 4).
+// Every lane still performs exactly the reference's own sequence of node tests / body terms, in its own order,
+// with its own decisions (results and counters are bitwise those of bvh_force_kernel).  What changes is WHEN: a
+// lane's state is the key (covered, level) of the entry it must visit next — `covered` = index of the entry's
+// first body — and along any lane's walk that key only grows in (covered, level) lexicographic order, which is
+// DFS pre-order.  The wave therefore sweeps the UNION of its 64 lanes' entries once, in key order: at each step
+// the record is wave-uniform (one scalar load instead of 64 divergent gathers), lanes whose key equals the
+// current one take part, the others wait.  Lanes cannot drift apart.  Union per wave at config 4: ~7.5k entries
+// vs ~4.3k per lane, so with few waves in flight (small N) the per-lane form is faster.
+// This form is bound by its serial chain and the CU's single scalar unit (~50 SALU instructions per step).
 // Measured and rejected: fetching both possible successors speculatively (scalar loads return out of order,
 // so every step waits for the not-taken, often cold, one: 26 vs 14 ms); a wave-private LDS window over a
 // pre-order copy of the tree filled by LDS-DMA (15.6 ms: refills cost more than the misses they replace);
@@ -654,7 +624,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
-                                                            uint32_t count, T theta2, uint32_t nlevels, uint32_t nnodes,
+                                                            uint32_t count, T theta2, uint32_t nlevels,
                                                             uint32_t* __restrict__ counters) {
   constexpr uint32_t DONE = 0xffffffffu;
   const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
@@ -666,16 +636,8 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     xs[k]  = x[uint64_t(i) * D + k];
     acc[k] = T(0);
   }
-  uint32_t key              = valid ? 0u : DONE;  // root: covered 0, level 0
-  const uint32_t leaf_level = nlevels;
+  uint32_t key = valid ? 0u : DONE;  // root: covered 0, level 0
   uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
-
-  // record index of a key (wave-uniform)
-  auto rec_index = [&](uint32_t k) -> uint64_t {
-    const uint32_t lv = k & 31u, cv = k >> 5;
-    return lv == leaf_level ? uint64_t(nnodes) + (cv >> 1) : uint64_t(((1u << lv) - 1u) + (cv >> (nlevels - lv)));
-  };
-
   uint32_t cur = 0;
 
   for (;;) {
@@ -694,40 +656,38 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       }
       return;
     }
-    const bool leaf      = level == leaf_level;
-    const tree_rec<T> rc = node[rec_index(cur)];  // wave-uniform address: one scalar load
+    const uint32_t shift = nlevels - level;  // 0 on the body level
+    const tree_rec<T> rc = node[((1u << level) - 1u) + (cov >> shift)];  // wave-uniform address: one scalar load
 
     // keys of the two possible successors
-    const uint32_t span = leaf ? 2u : (1u << (nlevels - level));
+    const uint32_t span = 1u << shift;
     const uint32_t ncov = cov + span;
-    // leaf -> parent + 1 (level - 1); left child -> sibling (same level); right child -> parent + 1  (src/bvh.h:272-281)
-    // (a node is a right child iff its position in the level, covered / span, is odd; the root counts as one)
-    const uint32_t nlev = (leaf || level == 0u || (cov & span)) ? level - 1u : level;
+    // left child -> sibling (same level); right child -> parent + 1 (level - 1)   (src/bvh.h:272-281)
+    // (an entry is a right child iff its position in the level, covered / span, is odd; the root counts as one)
+    const uint32_t nlev = (level == 0u || (cov & span)) ? level - 1u : level;
     const uint32_t ka   = (ncov >= sz) ? DONE : ((ncov << 5) | (nlev & 31u));
     const uint32_t kd   = cur + 1u;  // descend: same covered, level + 1  (src/bvh.h:283-286)
 
+    const bool body   = shift == 0u;
     const bool active = key == cur;
-    bool any_reject   = false;
-    if (leaf) {  // src/bvh.h:288-303 (cur is some lane's key, so at least one lane is active)
-      accumulate_leaf_pair_if<T, D>(active, acc, xs, rc);
-      if (COUNT && active) {
-        c_body += (cov != i) + uint32_t(cov + 1 < sz && cov + 1 != i);
-        ++c_leaf;
+    // a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
+    const bool approx = body || can_approximate<T, D>(xs, rc, theta2);
+    const bool accept = active && approx;
+    const bool reject = active && !approx;
+    if (COUNT && active) {
+      if (body) {
+        c_body += (cov != i);
+        c_leaf += !(cov & 1u);  // one leaf visit per body pair, counted at its first body
+      } else {
+        ++c_nodes;
+        c_mono += approx;
       }
-      key = active ? ka : key;
-    } else {
-      const bool approx = can_approximate<T, D>(xs, rc, theta2);
-      const bool accept = active && approx;
-      const bool reject = active && !approx;
-      if (COUNT && active) ++c_nodes;
-      if (__ballot(accept) != 0ull) {  // wave-uniform branch, per-lane predication of the weight
-        accumulate_monopole_if<T, D>(accept, acc, xs, rc);
-        if (COUNT && accept) ++c_mono;
-      }
-      key        = accept ? ka : (reject ? kd : key);
-      any_reject = __ballot(reject) != 0ull;
     }
-    if (any_reject) {
+    if (__ballot(accept) != 0ull) {  // wave-uniform branch, per-lane predication of the weight
+      accumulate_entry_if<T, D>(accept, acc, xs, rc);
+    }
+    key = accept ? ka : (reject ? kd : key);
+    if (__ballot(reject) != 0ull) {
       cur = kd;  // a lane opened the node: the left child is the smallest key any lane can now hold
     } else {
       // smallest key held by any lane: start from the finishing lanes' key, refine while some lane is behind it
@@ -843,8 +803,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   }
 #define NB_LAUNCH(KERN, CNT)                                                                                                 \
   hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a),                          \
-                     static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, s->count, th2, t->nlevels, t->nnodes, \
-                     t->counters)
+                     static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, s->count, th2, t->nlevels, t->counters)
   if (wave) {
     if (t->counters_on) NB_LAUNCH(bvh_force_wave_kernel, true);
     else NB_LAUNCH(bvh_force_wave_kernel, false);
@@ -906,7 +865,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(t->sort_blocks) + 1));  // + 256 digit totals
   NB_ALLOC(t->tmp, tmp_bytes);
-  NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs / 2)));  // internal nodes + leaf pairs
+  NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
 #undef NB_ALLOC
   *out = t;

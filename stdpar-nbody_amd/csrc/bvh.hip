@@ -636,13 +636,16 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     xs[k]  = x[uint64_t(i) * D + k];
     acc[k] = T(0);
   }
+  // A lane's key keeps counting past the end (covered >= sz means finished: such keys compare above every live
+  // one because `covered` sits in the high bits), so only lanes outside the shard need a sentinel.
   uint32_t key = valid ? 0u : DONE;  // root: covered 0, level 0
   uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
-  uint32_t cur = 0;
+
+  // wave-uniform position of the sweep, kept incrementally (the scalar unit is this kernel's bottleneck): level,
+  // first body `cov`, level-order index `idx` of the current entry; `cur` is the same position as a packed key
+  uint32_t level = 0, cov = 0, idx = 0, cur = 0;
 
   for (;;) {
-    cur                  = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; pin it to an SGPR
-    const uint32_t level = cur & 31u, cov = cur >> 5;
     if (cov >= sz) {  // every remaining key is >= cur: all lanes are finished
       if (valid) {
 #pragma unroll
@@ -656,16 +659,17 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       }
       return;
     }
-    const uint32_t shift = nlevels - level;  // 0 on the body level
-    const tree_rec<T> rc = node[((1u << level) - 1u) + (cov >> shift)];  // wave-uniform address: one scalar load
+    const tree_rec<T> rc = node[idx];  // wave-uniform address: one scalar load
 
-    // keys of the two possible successors
-    const uint32_t span = 1u << shift;
-    const uint32_t ncov = cov + span;
+    // the two possible successors
+    const uint32_t shift = nlevels - level;  // 0 on the body level
+    const uint32_t span  = 1u << shift;
+    const uint32_t ncov  = cov + span;
     // left child -> sibling (same level); right child -> parent + 1 (level - 1)   (src/bvh.h:272-281)
-    // (an entry is a right child iff its position in the level, covered / span, is odd; the root counts as one)
-    const uint32_t nlev = (level == 0u || (cov & span)) ? level - 1u : level;
-    const uint32_t ka   = (ncov >= sz) ? DONE : ((ncov << 5) | (nlev & 31u));
+    // (an entry is a right child iff its level-order index is even; the root counts as one)
+    const bool right    = (idx & 1u) == 0u;
+    const uint32_t nlev = right ? level - 1u : level;
+    const uint32_t ka   = (ncov << 5) | (nlev & 31u);
     const uint32_t kd   = cur + 1u;  // descend: same covered, level + 1  (src/bvh.h:283-286)
 
     const bool body   = shift == 0u;
@@ -688,17 +692,30 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     }
     key = accept ? ka : (reject ? kd : key);
     if (__ballot(reject) != 0ull) {
-      cur = kd;  // a lane opened the node: the left child is the smallest key any lane can now hold
+      // a lane opened the node: its left child is the smallest key any lane can now hold
+      cur   = kd;
+      level = level + 1u;
+      idx   = 2u * idx + 1u;
+    } else if (__ballot(key < ka) == 0ull) {
+      // nobody is behind the finishing lanes' key: follow the ascend rule incrementally
+      cur   = ka;
+      cov   = ncov;
+      idx   = right ? (idx >> 1) : idx + 1u;  // parent + 1 = (idx - 2) / 2 + 1 for an even idx ; sibling
+      level = nlev;
     } else {
-      // smallest key held by any lane: start from the finishing lanes' key, refine while some lane is behind it
+      // some lane waits at a smaller key (it jumped here from a deeper subtree): take the smallest and decode it
       uint32_t cand   = ka;
       uint64_t behind = __ballot(key < cand);
       while (behind) {
         cand   = __builtin_amdgcn_readlane(key, __builtin_ctzll(behind));
         behind = __ballot(key < cand);
       }
-      cur = cand;
+      cur   = cand;
+      level = cand & 31u;
+      cov   = cand >> 5;
+      idx   = ((1u << level) - 1u) + (cov >> (nlevels - level));
     }
+    cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR
   }
 }
 

@@ -811,9 +811,10 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th2 = th * th;  // src/bvh.h:252, in T
   const uint32_t blocks = (s->count + 63) / 64;
   auto* node = static_cast<const tree_rec<T>*>(t->node);
-  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain (crossover ~400k bodies
-  // on 256 CUs: 9.1 vs 9.5 ms at 500k, 6.2 vs 4.1 ms at 250k)
-  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= 400000u);
+  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured crossover on
+  // 256 CUs: f64 6.08 (sweep) vs 6.38 ms (per-lane) at 400k and 5.16 vs 4.72 ms at 300k; f32 4.79 vs 4.27 ms at 400k.
+  const uint32_t crossover = sizeof(T) == 8 ? 350000u : 600000u;
+  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;

@@ -63,8 +63,9 @@ inline int dispatch(int dtype, int dim, F&& f) {
 // i.e. one pow, one add and D divisions per pair.  On gfx950 FP64 transcendentals run at quarter
 // rate and do not overlap the FMA pipe (profiles/r01_valu_rates_microbench.txt), and an IEEE divide is
 // a ~10-instruction sequence, so the kernel evaluates   w = m_j / (r2*sqrt(r2) + eps)   once per pair
-// with two 2^-24 hardware seeds (v_rsq, v_rcp) each polished by one third-order step, then D FMAs.
-// Error budget vs the exact expression: < 2 ulp per term (tests/test_pair_math.py pins it).
+// with two 2^-24 hardware seeds (v_rsq, v_rcp) each polished by one Newton step, then D FMAs.
+// Error budget vs the exact expression: within [-2e-15, +4.1e-15] per term (see NBODY_PAIR_POLISH below;
+// tests/test_gpu_all_pairs.py::test_pair_term_accuracy pins the measured size).
 //
 // r2 must be > 0: callers fold TINY into the first FMA of r2 (r2 = fma(dx,dx,TINY)), which makes the
 // self term and coincident bodies evaluate to exactly 0 * (finite) = 0 — the value the reference
@@ -72,6 +73,17 @@ inline int dispatch(int dtype, int dim, F&& f) {
 // and no select (a v_cmp + 2 v_cndmask select costs ~5 FMA slots on this chip).
 template <typename T>
 struct pair_math;
+
+// NBODY_PAIR_POLISH: order of the polish applied to the two 2^-24 FP64 seeds.
+//   2 (default): Newton steps  s = h + h*e/2,  w = zm + zm*e2        17 full-rate ops + 2 transcendentals per pair.
+//      Per-term error bound: +3/8*e^2 (e <= 2^-23.2) - e2^2 (e2 <= 2^-24.4)  =>  within [-2e-15, +4.1e-15] relative.
+//      Measured on accelerations against the oracle in the SAME summation order: max 1.9e-15, mean signed 4e-17 (no
+//      bias) — the same size as the order-of-summation differences (2-3e-15) and 3 decades under the 1e-12 parity
+//      tolerance.  758.6 ms per force pass at N=2^20 (36.9 % of FP64 peak).
+//   3: third-order steps (+2 FMA): <= 2 ulp per term (max 3e-16 on accelerations), 814 ms (34.4 %).
+#ifndef NBODY_PAIR_POLISH
+  #define NBODY_PAIR_POLISH 2
+#endif
 
 template <>
 struct pair_math<double> {
@@ -81,15 +93,22 @@ struct pair_math<double> {
     double y0 = __builtin_amdgcn_rsq(r2);     // ~2^-24 relative
     double h  = r2 * y0;                      // ~sqrt(r2)
     double e  = __builtin_fma(-h, y0, 1.0);   // 1 - r2*y0^2
+#if NBODY_PAIR_POLISH >= 3
     double p  = __builtin_fma(e, 0.375, 0.5);
-    double g  = h * e;
-    double s  = __builtin_fma(g, p, h);       // sqrt(r2)*(1 + O(e^3))
+    double s  = __builtin_fma(h * e, p, h);   // sqrt(r2)*(1 + O(e^3))
+#else
+    double s  = __builtin_fma(h * 0.5, e, h); // sqrt(r2)*(1 - 3/8 e^2)
+#endif
     double d3 = __builtin_fma(r2, s, DBL_EPSILON);
     double z0 = __builtin_amdgcn_rcp(d3);     // ~2^-24 relative
     double e2 = __builtin_fma(-d3, z0, 1.0);
-    double q  = __builtin_fma(e2, e2, e2);    // e2 + e2^2
     double zm = z0 * mj;
+#if NBODY_PAIR_POLISH >= 3
+    double q  = __builtin_fma(e2, e2, e2);    // e2 + e2^2
     return __builtin_fma(zm, q, zm);          // mj/d3 * (1 + O(e2^3))
+#else
+    return __builtin_fma(zm, e2, zm);         // mj/d3 * (1 - e2^2)
+#endif
   }
 };
 

@@ -3,7 +3,7 @@ reference-generated fixtures.
 
 Tolerances (stated once, used everywhere below):
   * integer / copy / K3 leapfrog: bit-exact.
-  * double forces: |a_gpu - a_ref| <= 1e-12 * max|a_ref|  (the kernel's pair term is < 2 ulp; the rest is
+  * double forces: |a_gpu - a_ref| <= 1e-12 * max|a_ref|  (the kernel's pair term is within 4.1e-15; the rest is
     summation order: the reference sums j ascending in one chain, the kernel in 4 wave-partials).
     Two legitimate builds of the reference (-O2 vs -Ofast) differ by 3.6e-15 after one step.
   * double trajectories vs reference frames: rel 1e-11 of the position scale after <= 20 steps.
@@ -44,15 +44,19 @@ def test_all_pairs_force_vs_oracle(nb, oracle, dtype, dim):
         dev.close()
 
 
-def test_pair_term_accuracy_in_ulps(nb, oracle):
-    """split=1 sums in the reference's order, so what is left is the pair math: <= a few ulp of the largest term."""
+def test_pair_term_accuracy(nb, oracle):
+    """split=1 sums in the reference's order, so what is left is the pair math.  Bound of the default second-order polish:
+    [-2e-15, +4.1e-15] per term (csrc/common.hpp); measured 1.9e-15 on accelerations with no bias."""
     ref = oracle.build_model(1, 3, "galaxy", 4099)
     dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 4099))
     nb.configure_all_pairs(1, 1)
     dev.all_pairs_force()
     nb.configure_all_pairs(0, 0)
     oracle.all_pairs_force(ref)
-    assert maxrel(dev.download().a, ref.a) <= 2e-15
+    a = dev.download().a
+    assert maxrel(a, ref.a) <= 4.5e-15
+    na, nr = np.linalg.norm(a, axis=1), np.linalg.norm(ref.a, axis=1)
+    assert abs(np.mean((na - nr) / nr)) <= 5e-16  # no systematic bias
 
 
 def test_shard_windows_are_bitwise_identical(nb):

@@ -294,3 +294,36 @@ def test_pair_math_adversarial_separations(nb, oracle, dtype):
         bad = np.where(err > tol * np.maximum(mag, np.median(mag)))[0]
         assert bad.size == 0, (split, bad[:5], err[bad[:5]], mag[bad[:5]])
     nb.configure_all_pairs(0, 0)
+
+
+def test_torch_plumbing_path_equals_ctx_path(nb):
+    """bench.py's path (torch tensors' data_ptr() and torch's current stream passed through the C ABI, including the
+    shard-window form with v/a/ao holding only the owned rows) gives bitwise the result of the owning-context path."""
+    import torch
+    n, steps = 6000, 3
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    nb.run(dev, "all-pairs", steps)
+    ref = dev.download()
+    hs = nb.build_model(1, 3, "galaxy", n)
+    sim = nb.parallel.ShardedAllPairs(hs, 0, 1, torch_device=torch.device("cuda", 0))
+    for _ in range(steps):
+        sim.step()
+    torch.cuda.synchronize()
+    x, v, a = sim.gather_state()
+    assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
+    # two "ranks" emulated one after the other on one GPU: each owns half of the targets, positions merged by hand
+    sims = [nb.parallel.ShardedAllPairs(nb.build_model(1, 3, "galaxy", n), r, 2, torch_device=torch.device("cuda", 0)) for r in range(2)]
+    for s in sims:
+        s.exchange = False  # no process group here; the exchange is emulated below
+    for _ in range(steps):
+        for s in sims:
+            st = s.state()
+            s.ops.all_pairs_force(st, s._stream())
+            s.ops.accelerate_step(st, s._stream())
+        torch.cuda.synchronize()
+        for s in sims:      # what all_gather_into_tensor does
+            for o in sims:
+                s.x[o.first:o.first + o.count] = o.x[o.first:o.first + o.count]
+    torch.cuda.synchronize()
+    assert np.array_equal(sims[0].x.cpu().numpy(), ref.x) and np.array_equal(sims[1].x.cpu().numpy(), ref.x)
+    assert np.array_equal(np.concatenate([s.v.cpu().numpy() for s in sims]), ref.v)

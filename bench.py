@@ -160,6 +160,21 @@ def main():
             rec = json.load(open(pmc))
             if rec.get("n") == n and rec.get("gpus") == world:
                 traffic = rec.get("bytes_per_launch")
+        # rocprofv3 evidence for the dominant kernel (north_star: VALU-busy and HBM GB/s against the chip's peak),
+        # derived from the committed PMC passes of this same command (profiles/r01/, tools/profile_bench.sh) — not live
+        evidence = None
+        pmc_path = os.path.join(ROOT, "profiles", "r01", "bench_n1_pmc_all_pairs_force.json")
+        if world == 1 and n == (1 << 20) and os.path.exists(pmc_path):
+            c = json.load(open(pmc_path))
+            cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
+            prof_s = c.get("duration_ns_pmc_sq", k1_ms * 1e6) * 1e-9  # kernel duration inside the profiled pass
+            evidence = {
+                "source": "profiles/r01/bench_n1_pmc_all_pairs_force.json (rocprofv3 --pmc, separate passes)",
+                "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024),   # quad-cycles -> cycles, 1024 SIMDs
+                "valu_insts_per_wave_pair": c["SQ_INSTS_VALU"] / (n * n / 64.0),
+                "effective_clock_ghz": cycles / prof_s / 1e9,
+                "hbm_gbps": traffic / prof_s / 1e9 if traffic else None, "hbm_peak_gbps": 8000.0,
+            }
         out = {
             "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
             "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -172,6 +187,7 @@ def main():
             "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_kernel<double,3>", "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": k1_ms,
+                         "rocprof": evidence,
                          "note": "north_star forbids MFMA for this path; bound is the FP64 vector pipe "
                                  "(20 algorithmic flop per ordered pair, SURVEY 8d)"},
         }

@@ -56,6 +56,10 @@ typedef struct nbody_state {
   int32_t dim;     /* 2 | 3                                                         */
 } nbody_state;
 
+/* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major. */
+#define NBODY_HIP_ABI_VERSION 1000
+int nbody_abi_version(void);
+
 /* Last error message of the calling thread ("" if none). */
 const char* nbody_last_error(void);
 

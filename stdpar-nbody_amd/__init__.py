@@ -42,7 +42,7 @@ def build(verbose=False):
 
 # every symbol include/nbody_hip.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
-    "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
+    "nbody_abi_version", "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
     "nbody_accelerate_step", "nbody_calc_energies", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
     "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
@@ -61,6 +61,8 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise NbodyError(f"{LIB_PATH} is missing: run `make -C stdpar-nbody_amd` (or __graft_entry__.build())")
         L = C.CDLL(LIB_PATH)
+        if L.nbody_abi_version() // 1000 != 1:
+            raise NbodyError(f"{LIB_PATH} has ABI version {L.nbody_abi_version()}, this binding needs major version 1")
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_ctx_stream.restype = C.c_void_p
         L.nbody_bvh_nnodes.restype = C.c_uint32

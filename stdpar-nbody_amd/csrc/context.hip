@@ -36,6 +36,8 @@ struct nbody_ctx {
   hipStream_t stream = nullptr;
 };
 
+extern "C" int nbody_abi_version(void) { return NBODY_HIP_ABI_VERSION; }
+
 extern "C" const char* nbody_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int nbody_device_info(int device, char* arch_out, size_t arch_len, int* cu_count) {

@@ -189,6 +189,19 @@ def bvh_step_force(s, theta):
     assert r == 0
 
 
+def octree_step_force(s, theta, want_counts=False):
+    """clear, bounds, insert, multipoles, force (octree.h:321-326). Returns (counts or None, tree_size, root_mass)."""
+    t = np_dtype(s.dtype)
+    counts = np.zeros((s.n, 2), np.uint32) if want_counts else None
+    size = C.c_uint32()
+    root_mass = np.zeros(1, t)
+    r = lib().oracle_octree_step_force(s.dtype, s.dim, _p(s.m), _p(s.x), _p(s.a), C.c_double(s.c), C.c_uint32(s.n),
+                                       C.c_double(theta), _p(counts), C.byref(size), _p(root_mass))
+    if r != 0:
+        raise RuntimeError(f"oracle_octree_step_force failed ({r})")
+    return counts, size.value, root_mass[0]
+
+
 def executed_steps(steps, csv_detailed, warmup=10):
     """default mode runs max(steps, warmup) steps; --csv-detailed runs exactly `steps`
     (all_pairs.h:72-97, bvh.h:356-403, arguments.h:26)."""
@@ -205,6 +218,8 @@ def run(s, algorithm, nsteps, theta=0.5, collapsed_mode=1, frames=None):
             all_pairs_collapsed_force(s, collapsed_mode)
         elif algorithm == "bvh":
             bvh_step_force(s, theta)
+        elif algorithm == "octree":
+            octree_step_force(s, theta)
         else:
             raise ValueError(algorithm)
         accelerate_step(s)

@@ -268,3 +268,14 @@ int64_t oracle_build_model(int dtype, int dim, int workload, uint32_t n, void* m
   }
   return -1;
 }
+
+/* One octree force phase (octree.h:321-326).  counts: u32[sz][2] {nodes examined, terms} or NULL; tree_size and
+ * root_mass (T) may be NULL.  Returns -2 when the tree overflows its capacity (coincident bodies). */
+int oracle_octree_step_force(int dtype, int dim, const void* m, const void* x, void* a, double c, uint32_t sz, double theta,
+                             uint32_t* counts, uint32_t* tree_size, void* root_mass) {
+  int rc = 0;
+#define CALL(TT, S) rc = octree_step_force_##S((const TT*)m, (const TT*)x, (TT*)a, (TT)c, sz, (TT)theta, counts, tree_size, (TT*)root_mass)
+  DISPATCH(dtype, dim, CALL);
+#undef CALL
+  return rc < 0 ? -2 : 0;
+}

@@ -40,6 +40,11 @@ def print_state_cases():
                 for algo, theta in (("all-pairs", None), ("bvh", 0.0), ("bvh", 0.5)):
                     cases.append((dim, "double", algo, wl, n, 12 if n <= 64 else 5, theta))
     cases.append((2, "double", "all-pairs-collapsed", "uniform", 64, 12, None))
+    for dim in (2, 3):  # octree: the reference's default algorithm (src/arguments.h:28)
+        for wl in ("uniform", "galaxy"):
+            for n in (10, 64):
+                for theta in (0.0, 0.5):
+                    cases.append((dim, "double", "octree", wl, n, 12, theta))
     cases.append((3, "double", "all-pairs", "plummer", 64, 12, None))
     cases.append((3, "float", "all-pairs", "galaxy", 10, 5, None))
     return cases
@@ -54,6 +59,12 @@ def positions_cases():
                     for algo, theta in (("all-pairs", None), ("bvh", 0.0), ("bvh", 0.5)):
                         cases.append((dim, prec, algo, wl, n, 4, theta))
             cases.append((dim, prec, "all-pairs-collapsed", "uniform", 100, 4, None))
+            for wl in ("uniform", "galaxy"):
+                for n in (10, 257):
+                    for theta in (0.0, 0.5):
+                        cases.append((dim, prec, "octree", wl, n, 4, theta))
+    cases.append((3, "double", "octree", "plummer", 257, 4, 0.5))
+    cases.append((3, "double", "octree", "galaxy", 2000, 10, 0.5))
     cases.append((3, "double", "all-pairs", "plummer", 100, 4, None))
     cases.append((3, "double", "all-pairs", "galaxy", 1024, 20, None))
     cases.append((3, "double", "bvh", "galaxy", 1024, 20, 0.5))

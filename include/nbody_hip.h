@@ -136,6 +136,32 @@ int nbody_bvh_enable_counters(nbody_bvh* t, int on);
 int nbody_bvh_set_traversal(nbody_bvh* t, int mode);
 uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
 
+/* ---- octree Barnes-Hut (src/octree.h, the reference's default --algorithm) ---------------------------------
+ * The reference inserts bodies concurrently under per-node spin locks; only node NUMBERS depend on that order.
+ * Here the same spatial tree is built without locks (path keys -> radix sort -> breadth-first split), so results,
+ * tree size and visit counts equal the reference's.  Whole system only for the build phases; compute_force
+ * honours the shard window.  Errors found on the device (depth limit / node pool) surface in nbody_octree_info. */
+typedef struct nbody_octree nbody_octree;
+/* octree<T,N>::alloc / dealloc (src/octree.h:42-60); capacity = max(2^dim * n, 1000) nodes (src/system.h:30). */
+int  nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n);
+void nbody_octree_destroy(nbody_octree* t);
+/* octree::clear (src/octree.h:85-89): readies the tree for the next step. */
+int nbody_octree_clear(nbody_octree* t, void* stream);
+/* octree::compute_bounds (src/octree.h:93-112): root cube from the scalar min/max over all coordinates, +-1. */
+int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s, void* stream);
+/* octree::insert (src/octree.h:114-181). */
+int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* stream);
+/* octree::compute_tree (src/octree.h:183-224): masses and centres of mass, children summed in child order. */
+int nbody_octree_compute_tree(nbody_octree* t, void* stream);
+/* octree::compute_force (src/octree.h:226-263): a[i] = c * sum over the stackless walk with side/dx < theta. */
+int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream);
+/* Blocking.  tree_size = next_free_child_group (printed by --print-info, src/octree.h:314), root_mass = m[0].mass()
+ * as one T; either may be NULL.  Fails if the build hit the depth limit or exhausted the node pool. */
+int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, void* stream);
+/* Test/diagnostic: per-body {nodes examined, terms accumulated} u32[n][2] of the last compute_force. */
+int nbody_octree_enable_counters(nbody_octree* t, int on);
+int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream);
+
 /* ---- owning context (device mirrors of a host System), used by the C++ CLI host ------------------ */
 
 typedef struct nbody_ctx nbody_ctx;

@@ -45,7 +45,9 @@ ABI_SYMBOLS = [
     "nbody_abi_version", "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
     "nbody_accelerate_step", "nbody_calc_energies", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
-    "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
+    "nbody_octree_create", "nbody_octree_destroy", "nbody_octree_clear", "nbody_octree_compute_bounds", "nbody_octree_insert",
+    "nbody_octree_compute_tree", "nbody_octree_compute_force", "nbody_octree_info", "nbody_octree_enable_counters",
+    "nbody_octree_read_counters", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
     "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
 ]
@@ -192,6 +194,56 @@ class Bvh:
         return out
 
 
+class Octree:
+    """octree<T,N> (src/octree.h) on the device."""
+
+    def __init__(self, dtype, dim, n):
+        self.h = C.c_void_p()
+        self.dtype, self.dim, self.n = dtype, dim, n
+        _check(lib().nbody_octree_create(C.byref(self.h), dtype, dim, C.c_uint32(n)))
+
+    def close(self):
+        if self.h:
+            lib().nbody_octree_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def clear(self, stream=None):
+        _check(lib().nbody_octree_clear(self.h, C.c_void_p(stream)))
+
+    def compute_bounds(self, st, stream=None):
+        _check(lib().nbody_octree_compute_bounds(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def insert(self, st, stream=None):
+        _check(lib().nbody_octree_insert(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def compute_tree(self, stream=None):
+        _check(lib().nbody_octree_compute_tree(self.h, C.c_void_p(stream)))
+
+    def compute_force(self, st, theta, stream=None):
+        _check(lib().nbody_octree_compute_force(self.h, C.byref(st), C.c_double(theta), C.c_void_p(stream)))
+
+    def info(self, stream=None):
+        """(tree size = next_free_child_group, root mass); raises if the build hit the depth limit / node pool."""
+        size = C.c_uint32()
+        mass = np.zeros(1, np_dtype(self.dtype))
+        _check(lib().nbody_octree_info(self.h, C.byref(size), _p(mass), C.c_void_p(stream)))
+        return size.value, mass[0]
+
+    def enable_counters(self, on=True):
+        _check(lib().nbody_octree_enable_counters(self.h, 1 if on else 0))
+
+    def read_counters(self, stream=None):
+        out = np.zeros((self.n, 2), np.uint32)
+        _check(lib().nbody_octree_read_counters(self.h, _p(out), C.c_size_t(out.nbytes), C.c_void_p(stream)))
+        return out
+
+
 class DeviceSystem:
     """Owning device mirror of a System<T,N>; phase methods mirror the calls of the reference drivers."""
 
@@ -201,6 +253,7 @@ class DeviceSystem:
         _check(lib().nbody_create(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
         self.stream = lib().nbody_ctx_stream(self.h)
         self._bvh = None
+        self._octree = None
 
     @classmethod
     def from_host(cls, hs, device=0):
@@ -212,6 +265,9 @@ class DeviceSystem:
         if self._bvh is not None:
             self._bvh.close()
             self._bvh = None
+        if self._octree is not None:
+            self._octree.close()
+            self._octree = None
         if self.h:
             lib().nbody_destroy(self.h)
             self.h = C.c_void_p()
@@ -276,6 +332,21 @@ class DeviceSystem:
         if self._bvh is None:
             self._bvh = Bvh(self.dtype, self.dim, self.n)
         return self._bvh
+
+    @property
+    def octree(self):
+        if self._octree is None:
+            self._octree = Octree(self.dtype, self.dim, self.n)
+        return self._octree
+
+    def octree_force(self, theta):
+        """One force phase of run_octree (src/octree.h:321-326)."""
+        st, t = self.state(), self.octree
+        t.clear(self.stream)
+        t.compute_bounds(st, self.stream)
+        t.insert(st, self.stream)
+        t.compute_tree(self.stream)
+        t.compute_force(st, theta, self.stream)
 
     def bvh_force(self, theta):
         """One force phase of run_bvh (src/bvh.h:382-393)."""
@@ -342,6 +413,8 @@ def run(dev, algorithm, nsteps, theta=0.5):
             dev.all_pairs_collapsed_force()
         elif algorithm == "bvh":
             dev.bvh_force(theta)
+        elif algorithm == "octree":
+            dev.octree_force(theta)
         else:
             raise ValueError(algorithm)
         dev.accelerate_step()

@@ -16,6 +16,7 @@
 // against the oracle; tree COMs/widths are bit-exact too (FP contraction is off in the build and in
 // the opening test), only the accumulated force uses the fast pair math of common.hpp.
 #include "common.hpp"
+#include "radix_sort.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -229,129 +230,6 @@ __global__ __launch_bounds__(kB) void hilbert_keys_kernel(const T* __restrict__ 
     cell[k] = uint32_t(static_cast<long long>(q));
   }
   keys[i] = hilbert_key<D>(cell);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6 stable LSD radix sort of (key, index), 8 bits per pass  (replaces std::sort, src/bvh.h:55-94;
-// the reference sort is unstable, ties here keep original index order)
-// ------------------------------------------------------------------------------------------------
-constexpr int kSortIPT  = 8;  // keys per lane
-constexpr int kSortTile = kB * kSortIPT;  // 2048 keys per block; wave w owns keys [w*512, w*512+512)
-
-__global__ __launch_bounds__(kB) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
-                                                        uint32_t* __restrict__ hist, uint32_t nblk) {
-  __shared__ uint32_t cnt[256];
-  cnt[threadIdx.x] = 0;
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < kSortIPT; ++q) {
-    uint64_t i = uint64_t(blockIdx.x) * kSortTile + q * kB + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
-  }
-  __syncthreads();
-  hist[uint64_t(threadIdx.x) * nblk + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// Exclusive scan of one digit's row hist[d][0..nblk) (one block per digit, coalesced) + the digit's total.
-// The scan ACROSS digits (256 totals) is folded into the scatter kernel, so a pass has no serial kernel.
-__global__ __launch_bounds__(kB) void radix_scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
-                                                             uint32_t* __restrict__ totals) {
-  __shared__ uint32_t wsum[kB / 64];
-  __shared__ uint32_t carry;
-  uint32_t* row  = hist + uint64_t(blockIdx.x) * nblk;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  for (uint32_t base = 0; base < nblk; base += kB) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < nblk ? row[i] : 0u;
-    uint32_t inc     = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t o = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += o;
-    }
-    if (lane == 63) wsum[wave] = inc;
-    __syncthreads();
-    uint32_t pre = carry;
-    for (int w = 0; w < wave; ++w) pre += wsum[w];
-    if (i < nblk) row[i] = pre + inc - v;
-    __syncthreads();
-    if (threadIdx.x == kB - 1) carry = pre + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
-}
-
-__global__ __launch_bounds__(kB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
-                                                           uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
-                                                           uint32_t n, int shift, const uint32_t* __restrict__ hist,
-                                                           const uint32_t* __restrict__ totals, uint32_t nblk) {
-  __shared__ uint32_t wcnt[kB / 64][256];
-  __shared__ uint32_t dbase[256];  // exclusive scan of the 256 digit totals
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int q = threadIdx.x; q < (kB / 64) * 256; q += kB) (&wcnt[0][0])[q] = 0;
-  __syncthreads();
-
-  uint64_t key[kSortIPT];
-  uint32_t pay[kSortIPT], rank[kSortIPT];
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-#pragma unroll
-  for (int s = 0; s < kSortIPT; ++s) {
-    uint64_t i       = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
-    const bool valid = i < n;
-    key[s]           = valid ? keys_in[i] : 0ull;
-    pay[s]           = valid ? (idx_in ? idx_in[i] : uint32_t(i)) : 0u;
-    const uint32_t d = uint32_t(key[s] >> shift) & 255u;
-    // lanes of this strip holding the same digit
-    uint64_t same = __ballot(valid);
-#pragma unroll
-    for (int b = 0; b < 8; ++b) {
-      const bool bit      = (d >> b) & 1u;
-      const uint64_t vote = __ballot(valid && bit);
-      same &= bit ? vote : ~vote;
-    }
-    const uint32_t before = __popcll(same & lt_mask);
-    const uint32_t base   = wcnt[wave][d];
-    rank[s]               = base + before;
-    __builtin_amdgcn_wave_barrier();
-    if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
-    __builtin_amdgcn_wave_barrier();
-  }
-  {  // digit = threadIdx.x: exclusive scan of totals[0..255]; within a wave here, wave offsets after the barrier
-    const uint32_t v = totals[threadIdx.x];
-    uint32_t inc     = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      uint32_t o = __shfl_up(inc, off, 64);
-      if (lane >= off) inc += o;
-    }
-    dbase[threadIdx.x] = inc - v;
-  }
-  __syncthreads();
-  // digit = threadIdx.x: turn per-wave counts into global bases
-  {
-    uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += dbase[w * 64 + 63] + totals[w * 64 + 63];  // totals of the earlier 64-digit groups
-    uint32_t run = woff + dbase[threadIdx.x] + hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
-#pragma unroll
-    for (int w = 0; w < kB / 64; ++w) {
-      uint32_t cw          = wcnt[w][threadIdx.x];
-      wcnt[w][threadIdx.x] = run;
-      run += cw;
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int s = 0; s < kSortIPT; ++s) {
-    uint64_t i = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
-    if (i < n) {
-      const uint32_t d   = uint32_t(key[s] >> shift) & 255u;
-      const uint32_t pos = wcnt[wave][d] + rank[s];
-      keys_out[pos]      = key[s];
-      idx_out[pos]       = pay[s];
-    }
-  }
 }
 
 // gather all five state arrays through the permutation into tmp (then copied back)
@@ -750,23 +628,11 @@ static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   NB_HIP(hipGetLastError());
   // keys[0] must survive for nbody_bvh_read(what=0): sort from a copy
   NB_HIP(hipMemcpyAsync(t->keys[1], t->keys[0], sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, st));
-  // ping-pong between keys[1] and tmp-backed key buffer is avoided: use a third buffer carved from tmp
-  uint64_t* kbuf[2] = {t->keys[1], reinterpret_cast<uint64_t*>(t->tmp)};
-  const uint32_t nblk = t->sort_blocks;
+  // the sort ping-pongs between keys[1] and a key buffer carved from tmp (keys[0] is kept for nbody_bvh_read)
+  uint64_t* kbuf[2]   = {t->keys[1], reinterpret_cast<uint64_t*>(t->tmp)};
   const int key_bits  = (D == 2) ? 64 : 63;
   int cur             = 0;
-  const uint32_t* idx_in = nullptr;
-  for (int shift = 0; shift < key_bits; shift += 8) {
-    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], n, shift, t->hist, nblk);
-    NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kB), 0, st, t->hist, nblk, t->hist + 256u * size_t(nblk));
-    NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kB), 0, st, kbuf[cur], idx_in, kbuf[cur ^ 1], t->idx[cur ^ 1], n,
-                       shift, t->hist, t->hist + 256u * size_t(nblk), nblk);
-    NB_HIP(hipGetLastError());
-    cur ^= 1;
-    idx_in = t->idx[cur];
-  }
+  if (int r = radix_sort_pairs(kbuf, t->idx, n, key_bits, t->hist, st, &cur)) return r;
   t->final_buf = cur;
   // permute the state in place: gather into tmp, copy back
   T* tmp = static_cast<T*>(t->tmp);

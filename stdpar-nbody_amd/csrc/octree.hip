@@ -1,0 +1,634 @@
+// Octree Barnes-Hut for gfx950 — replaces src/octree.h of the reference (its default --algorithm).
+//
+// The reference builds the tree by concurrent insertion with per-node spin locks and a bump allocator
+// (src/octree.h:114-181) and needs parallel forward progress (`par`); node NUMBERS depend on thread timing, but
+// everything observable does not: a cell is split iff it holds >= 2 bodies, children are visited in hyperant order
+// (src/octree.h:63-71), and a node's monopole is the sum of its 2^D children in child order (src/octree.h:205-216).
+// So the tree is rebuilt here WITHOUT locks, deterministically:
+//   bounds    scalar min/max over all coordinates (src/octree.h:93-112)
+//   keys      every body walks the implicit cell hierarchy on its own, replaying the reference's exact
+//             `divide[i] += (2*(pos[i] > divide[i]) - 1) * half_length` chain (src/octree.h:127-138), and records the
+//             hyperant taken at each of MAXL levels: a 63/64-bit path key
+//   sort      stable LSD radix sort of (key, body) — bodies of a cell are then contiguous
+//   build     breadth first, one launch per level: an internal cell [start, end) finds its 2^D child ranges by binary
+//             search on the next key digit; empty / single-body children become leaves, the others are queued for
+//             the next level.  Children are allocated after their parents, as the traversal requires
+//             (src/octree.h:248-249)
+//   multipoles  one launch per level, deepest first (src/octree.h:183-224, without the latch)
+//   force     the reference's stackless walk per body (src/octree.h:226-263); the opening test
+//             side/(sqrt(d2)+eps) < theta is evaluated with IEEE sqrt and divide so that decisions (and the per-body
+//             visit counters) are bit-exact; the accepted term m*(xj-x)/dx^3 uses one polished v_rcp_f64.
+// Depth limit: MAXL = 21 (3D) / 32 (2D) levels, i.e. bodies closer than root_side/2^MAXL in every coordinate are
+// reported as an error (the reference keeps splitting until its node pool overflows).
+#include "common.hpp"
+#include "radix_sort.hpp"
+
+#include <cstdlib>
+#include <cstring>
+
+namespace nbody {
+
+constexpr int kOB            = 256;
+constexpr uint32_t kOtEmpty  = 0xffffffffu;  // src/octree.h:37
+constexpr uint32_t kOtBody   = 0xfffffffeu;  // src/octree.h:38
+constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u;
+
+template <int D>
+constexpr int kMaxLevels = D == 3 ? 21 : 32;
+
+struct ot_cell {  // an internal cell waiting to be split: its node index and its range of sorted bodies
+  uint32_t node, start, end;
+};
+
+template <typename T>
+__device__ __forceinline__ T ot_fmin(T a, T b) {
+  if constexpr (sizeof(T) == 4) return __builtin_fminf(a, b);
+  else return __builtin_fmin(a, b);
+}
+template <typename T>
+__device__ __forceinline__ T ot_fmax(T a, T b) {
+  if constexpr (sizeof(T) == 4) return __builtin_fmaxf(a, b);
+  else return __builtin_fmax(a, b);
+}
+
+// ---- bounds (src/octree.h:93-112) -----------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void ot_block_minmax(T& lo, T& hi, T* out2) {
+  __shared__ T red[2][kOB / 64];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = ot_fmin(lo, __shfl_xor(lo, off, 64));
+    hi = ot_fmax(hi, __shfl_xor(hi, off, 64));
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = lo;
+    red[1][wave] = hi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T l = red[0][0], h = red[1][0];
+    for (int w = 1; w < kOB / 64; ++w) {
+      l = ot_fmin(l, red[0][w]);
+      h = ot_fmax(h, red[1][w]);
+    }
+    out2[0] = l;
+    out2[1] = h;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kOB) void ot_bounds_partial_kernel(const T* __restrict__ x, uint64_t nelem, T* __restrict__ partials) {
+  T lo = T(0), hi = T(0);  // the reduction starts from (0, 0): the root cube always contains the origin
+  for (uint64_t e = uint64_t(blockIdx.x) * kOB + threadIdx.x; e < nelem; e += uint64_t(gridDim.x) * kOB) {
+    const T p = x[e];
+    lo        = ot_fmin(lo, p);
+    hi        = ot_fmax(hi, p);
+  }
+  ot_block_minmax(lo, hi, partials + 2 * blockIdx.x);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_bounds_final_kernel(const T* __restrict__ partials, uint32_t nblk, T* __restrict__ root) {
+#pragma clang fp contract(off)
+  __shared__ T res[2];
+  T lo = T(0), hi = T(0);
+  for (uint32_t b = threadIdx.x; b < nblk; b += kOB) {
+    lo = ot_fmin(lo, partials[2 * b]);
+    hi = ot_fmax(hi, partials[2 * b + 1]);
+  }
+  ot_block_minmax(lo, hi, res);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T mx = res[1], mn = res[0];
+    mx += T(1);  // "adjust boundary"
+    mn -= T(1);
+    const T divide = (mx + mn) / T(2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) root[k] = divide;  // root_x = splat(divide)
+    root[D] = mx - mn;                             // root_side_length
+  }
+}
+
+// ---- path keys (src/octree.h:127-138 replayed per body) ------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, uint32_t n, const T* __restrict__ root,
+                                                      uint64_t* __restrict__ keys) {
+#pragma clang fp contract(off)
+  const uint64_t i = uint64_t(blockIdx.x) * kOB + threadIdx.x;
+  if (i >= n) return;
+  T pos[D], divide[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    pos[k]    = x[i * D + k];
+    divide[k] = root[k];
+  }
+  T side       = root[D];
+  uint64_t key = 0;
+  for (int l = 0; l < kMaxLevels<D>; ++l) {
+    const T half = side / T(4);  // /2 for the child's side, /2 for its half length
+    uint32_t cp  = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const int gt = pos[k] > divide[k];
+      cp |= uint32_t(gt) << k;
+      divide[k] += T(2 * gt - 1) * half;
+    }
+    side /= T(2);
+    key = (key << D) | cp;
+  }
+  keys[i] = key;
+}
+
+// ---- breadth-first build --------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, uint32_t* __restrict__ first_child,
+                                     src_rec<T, D>* __restrict__ mono, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
+                                     uint32_t* __restrict__ flags) {
+  if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
+  if (threadIdx.x == 0) {
+    flags[0] = 0;
+    if (n >= 2) {  // the root holds >= 2 bodies: it is the first cell to split
+      cells[0]     = ot_cell{0u, 0u, n};
+      lvl_count[0] = 1;
+    } else {  // a single body stays in the root (src/octree.h:140-145)
+      src_rec<T, D> r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r.p[k] = k < D ? x[k] : T(0);
+      r.m            = m[0];
+      mono[0]        = r;
+      first_child[0] = kOtBody;
+    }
+  }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
+                                                             const uint32_t* __restrict__ sidx, const T* __restrict__ m,
+                                                             const T* __restrict__ x, uint32_t* __restrict__ first_child,
+                                                             uint32_t* __restrict__ parent, src_rec<T, D>* __restrict__ mono,
+                                                             ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
+                                                             uint32_t* __restrict__ flags, uint32_t capacity, uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  const uint32_t count   = lvl_count[level];
+  const uint32_t k       = blockIdx.x * kOB + threadIdx.x;
+  if (k >= count) return;
+  uint32_t base = 0;  // cells of the shallower levels = rank of this level's first cell
+  for (int j = 0; j < level; ++j) base += lvl_count[j];
+  const uint32_t rank = base + k;
+  const ot_cell cell  = cells[rank];
+  const uint32_t fc   = 1u + rank * NCH;  // its sibling group (the reference's bump allocator hands out the same shape)
+  if (level >= kMaxLevels<D>) {           // >= 2 bodies share every key digit: deeper than the keys resolve
+    atomicOr(flags, kFlagDepth);
+    first_child[cell.node] = kOtEmpty;
+    return;
+  }
+  if (fc + NCH > capacity) {
+    atomicOr(flags, kFlagCapacity);
+    first_child[cell.node] = kOtEmpty;
+    return;
+  }
+  first_child[cell.node] = fc;
+  parent[rank]           = cell.node;  // parent[sg(fc)], sg(fc) = (fc - 1) / 2^D = rank
+
+  // child ranges: bodies are sorted by key, so the bodies of hyperant c are those whose digit at this level is c
+  const int shift = D * (kMaxLevels<D> - 1 - level);
+  uint32_t bound[NCH + 1];
+  bound[0]   = cell.start;
+  bound[NCH] = cell.end;
+#pragma unroll
+  for (uint32_t c = 1; c < NCH; ++c) {  // first position whose digit is >= c
+    uint32_t lo = bound[c - 1], hi = cell.end;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (((skeys[mid] >> shift) & (NCH - 1)) < c) lo = mid + 1;
+      else hi = mid;
+    }
+    bound[c] = lo;
+  }
+  const uint32_t next_base = base + count;
+#pragma unroll
+  for (uint32_t c = 0; c < NCH; ++c) {
+    const uint32_t cnt = bound[c + 1] - bound[c];
+    const uint32_t ci  = fc + c;
+    src_rec<T, D> r;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) r.p[q] = T(0);
+    r.m = T(0);
+    if (cnt == 0) {  // empty leaf: zero monopole (src/octree.h:77-83)
+      first_child[ci] = kOtEmpty;
+      mono[ci]        = r;
+    } else if (cnt == 1) {  // leaf with one body (src/octree.h:140-145, :163-165)
+      const uint64_t b = sidx[bound[c]];
+#pragma unroll
+      for (int q = 0; q < D; ++q) r.p[q] = x[b * D + q];
+      r.m             = m[b];
+      first_child[ci] = kOtBody;
+      mono[ci]        = r;
+    } else {  // >= 2 bodies: split it on the next level
+      const uint32_t pos = atomicAdd(&lvl_count[level + 1], 1u);
+      if (next_base + pos < max_cells) {
+        cells[next_base + pos] = ot_cell{ci, bound[c], bound[c + 1]};
+      } else {
+        atomicOr(flags, kFlagCapacity);
+        first_child[ci] = kOtEmpty;
+        mono[ci]        = r;
+      }
+    }
+  }
+}
+
+// ---- multipoles (src/octree.h:205-216) ---------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, const uint32_t* __restrict__ first_child,
+                                                                 src_rec<T, D>* __restrict__ mono, const ot_cell* __restrict__ cells,
+                                                                 const uint32_t* __restrict__ lvl_count) {
+#pragma clang fp contract(off)
+  constexpr uint32_t NCH = 1u << D;
+  const uint32_t count   = lvl_count[level];
+  const uint32_t k       = blockIdx.x * kOB + threadIdx.x;
+  if (k >= count) return;
+  uint32_t base = 0;
+  for (int j = 0; j < level; ++j) base += lvl_count[j];
+  const uint32_t node = cells[base + k].node;
+  const uint32_t fc   = first_child[node];
+  if (fc == kOtEmpty || fc == kOtBody) return;  // only after an overflow flag
+  T mass = T(0), xx[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) xx[q] = T(0);
+  for (uint32_t c = 0; c < NCH; ++c) {  // child order; empty children add (0, 0)
+    const src_rec<T, D> ch = mono[fc + c];
+    mass += ch.m;
+#pragma unroll
+    for (int q = 0; q < D; ++q) xx[q] += ch.m * ch.p[q];
+  }
+  src_rec<T, D> r;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) r.p[q] = q < D ? xx[q < D ? q : 0] / mass : T(0);
+  r.m        = mass;
+  mono[node] = r;
+}
+
+// ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t ot_xcd_contiguous_block(uint32_t b, uint32_t nblocks) {
+  const uint32_t q = nblocks / 8u, r = nblocks % 8u, xcd = b % 8u, slot = b / 8u;
+  return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
+}
+
+template <typename T>
+__device__ __forceinline__ T ot_sqrt(T v) {
+  if constexpr (sizeof(T) == 4) return __builtin_sqrtf(v);  // correctly rounded (HIP default for f32 sqrt/div)
+  else return __builtin_sqrt(v);
+}
+template <typename T>
+__device__ __forceinline__ T ot_recip(T d) {  // 1/d to ~2e-15 (f64: seed + one Newton step) / ~1 ulp (f32)
+  if constexpr (sizeof(T) == 4) {
+    return __builtin_amdgcn_rcpf(d);
+  } else {
+    const double z0 = __builtin_amdgcn_rcp(d);
+    return __builtin_fma(z0, __builtin_fma(-d, z0, 1.0), z0);
+  }
+}
+
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_kernel(const uint32_t* __restrict__ first_child, const uint32_t* __restrict__ parent,
+                                                      const src_rec<T, D>* __restrict__ mono, const uint32_t* __restrict__ sidx,
+                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                                      uint32_t count, T theta, const T* __restrict__ root,
+                                                      uint32_t* __restrict__ counters) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr T eps        = sizeof(T) == 4 ? T(FLT_EPSILON) : T(DBL_EPSILON);
+  // lanes take bodies in key order (spatially adjacent bodies walk nearly the same nodes); XCD-contiguous blocks
+  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  if (t >= sz) return;
+  const uint32_t body = sidx[t];
+  if (body < first || body - first >= count) return;
+  T xi[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xi[k]  = x[uint64_t(body) * D + k];
+    acc[k] = T(0);
+  }
+  uint32_t idx = 0;
+  T side       = root[D];
+  bool fwd     = true;
+  uint32_t c_nodes = 0, c_terms = 0;
+  uint32_t guard = 0;  // a well-formed tree is left after < 2*capacity steps; never spin on a damaged one
+  while (idx != kOtEmpty && ++guard != 0xfffffff0u) {
+    // next_node (src/octree.h:63-71): next sibling, or the parent after the last sibling
+    uint32_t next;
+    if (idx == 0) {
+      next = kOtEmpty;
+    } else {
+      const uint32_t sg = (idx - 1u) / NCH, cp = (idx - 1u) % NCH;
+      next = cp == NCH - 1u ? parent[sg] : idx + 1u;
+    }
+    if (fwd) {  // arrived from a parent or a sibling: examine the node
+      const src_rec<T, D> mj = mono[idx];
+      const uint32_t fc      = first_child[idx];
+      T dx;
+      bool take;
+      {
+#pragma clang fp contract(off)
+        T d2 = T(0);  // dist(x, xj) = sqrt(dist2) + eps, src/vec.h:232-246
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const T di = xi[k] - mj.p[k];
+          d2         = d2 + di * di;
+        }
+        dx   = ot_sqrt(d2) + eps;
+        take = fc == kOtEmpty || fc == kOtBody || side / dx < theta;  // IEEE divide: decisions are the reference's
+      }
+      if (COUNT) ++c_nodes;
+      if (take) {  // a += mj * (xj - x) / (dx*dx*dx); the body's own leaf and empty leaves add exactly 0
+        const T w = mj.m * ot_recip((dx * dx) * dx);
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, mj.p[k] - xi[k], acc[k]);
+        if (COUNT) ++c_terms;
+      } else {  // visit the children
+        next = fc;
+        side = side / T(2);
+      }
+    }
+    fwd  = next > idx;  // children are allocated after their parent
+    side = fwd ? side : side * T(2);
+    idx  = next;
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
+  if (COUNT) {
+    counters[uint64_t(body) * 2 + 0] = c_nodes;
+    counters[uint64_t(body) * 2 + 1] = c_terms;
+  }
+}
+
+}  // namespace nbody
+
+// ---- host side / C ABI -----------------------------------------------------------------------------------------------
+struct nbody_octree {
+  int dtype = 0, dim = 0;
+  uint32_t n = 0, capacity = 0, max_cells = 0, bounds_blocks = 0;
+  size_t tsz = 0;
+  void* root       = nullptr;  // T[D+1]: root_x (D), root_side_length
+  void* partials   = nullptr;
+  uint64_t* keys[2] = {nullptr, nullptr};
+  uint32_t* idx[2]  = {nullptr, nullptr};
+  uint32_t* hist   = nullptr;
+  uint32_t* first_child = nullptr;
+  uint32_t* parent = nullptr;
+  void* mono       = nullptr;  // src_rec<T,D>[capacity]
+  nbody::ot_cell* cells = nullptr;
+  uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
+  uint32_t* counters = nullptr;
+  int sorted_buf   = 0;
+  bool counters_on = false, have_bounds = false, inserted = false, have_tree = false;
+};
+
+using namespace nbody;
+
+namespace nbody {
+
+static int ot_check(const nbody_octree* t, const nbody_state* s) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (int r = check_state(s)) return r;
+  NB_ARG(t->dtype == s->dtype && t->dim == s->dim && t->n == s->sz,
+         "octree was created for (dtype=%d, dim=%d, n=%u), state is (%d, %d, %u)", t->dtype, t->dim, t->n, s->dtype, s->dim, s->sz);
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int ot_bounds_run(nbody_octree* t, const nbody_state* s, hipStream_t st) {
+  hipLaunchKernelGGL((ot_bounds_partial_kernel<T>), dim3(t->bounds_blocks), dim3(kOB), 0, st, static_cast<const T*>(s->x),
+                     uint64_t(s->sz) * D, static_cast<T*>(t->partials));
+  NB_HIP(hipGetLastError());
+  hipLaunchKernelGGL((ot_bounds_final_kernel<T, D>), dim3(1), dim3(kOB), 0, st, static_cast<const T*>(t->partials),
+                     t->bounds_blocks, static_cast<T*>(t->root));
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) {
+  constexpr uint32_t NCH = 1u << D;
+  const uint32_t n       = s->sz;
+  auto* mono             = static_cast<src_rec<T, D>*>(t->mono);
+  hipLaunchKernelGGL((ot_keys_kernel<T, D>), dim3((n + kOB - 1) / kOB), dim3(kOB), 0, st, static_cast<const T*>(s->x), n,
+                     static_cast<const T*>(t->root), t->keys[0]);
+  NB_HIP(hipGetLastError());
+  int fin = 0;
+  if (int r = radix_sort_pairs(t->keys, t->idx, n, D == 3 ? 63 : 64, t->hist, st, &fin)) return r;
+  t->sorted_buf = fin;
+  uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
+  hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
+                     static_cast<const T*>(s->x), t->first_child, mono, t->cells, t->lvl_count, flags);
+  NB_HIP(hipGetLastError());
+  uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
+  for (int l = 0; l <= kMaxLevels<D>; ++l) {
+    const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
+    hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
+                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), t->first_child,
+                       t->parent, mono, t->cells, t->lvl_count, flags, t->capacity, t->max_cells);
+    NB_HIP(hipGetLastError());
+    if (width < (uint64_t(1) << 40)) width *= NCH;
+  }
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int ot_tree_run(nbody_octree* t, hipStream_t st) {
+  constexpr uint32_t NCH = 1u << D;
+  auto* mono             = static_cast<src_rec<T, D>*>(t->mono);
+  for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
+    uint64_t width = 1;
+    for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
+    const uint64_t cap_l = width < uint64_t(t->n / 2 + 1) ? width : uint64_t(t->n / 2 + 1);
+    hipLaunchKernelGGL((ot_multipole_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
+                       t->first_child, mono, t->cells, t->lvl_count);
+    NB_HIP(hipGetLastError());
+  }
+  return NBODY_OK;
+}
+
+template <typename T, int D>
+static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hipStream_t st) {
+  if (s->count == 0) return NBODY_OK;
+  const uint32_t blocks = (s->sz + 63) / 64;
+  auto* mono            = static_cast<const src_rec<T, D>*>(t->mono);
+#define NB_OT_ARGS                                                                                                              \
+  t->first_child, t->parent, mono, t->idx[t->sorted_buf], static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), \
+   s->sz, s->first, s->count, static_cast<T>(theta), static_cast<const T*>(t->root), t->counters
+  if (t->counters_on) hipLaunchKernelGGL((ot_force_kernel<T, D, true>), dim3(blocks), dim3(64), 0, st, NB_OT_ARGS);
+  else hipLaunchKernelGGL((ot_force_kernel<T, D, false>), dim3(blocks), dim3(64), 0, st, NB_OT_ARGS);
+#undef NB_OT_ARGS
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
+}  // namespace nbody
+
+extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n) {
+  NB_ARG(out != nullptr, "out is NULL");
+  *out = nullptr;
+  NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
+  NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
+  NB_ARG(n >= 1 && n <= (1u << 28), "octree needs 1 <= n <= 2^28 (got %u)", n);
+  auto* t  = new nbody_octree;
+  t->dtype = dtype;
+  t->dim   = dim;
+  t->n     = n;
+  t->tsz   = dtype == NBODY_F32 ? 4 : 8;
+  const uint32_t nch = 1u << dim;
+  const uint64_t cap = uint64_t(nch) * n < 1000 ? 1000 : uint64_t(nch) * n;  // System::max_tree_node_size (src/system.h:30)
+  t->capacity        = uint32_t(cap);
+  t->max_cells       = t->capacity / nch + 1;
+  t->bounds_blocks   = uint32_t((uint64_t(n) * dim + kOB * 8 - 1) / (kOB * 8));
+  if (t->bounds_blocks > 1024) t->bounds_blocks = 1024;
+  const int maxl = dim == 3 ? kMaxLevels<3> : kMaxLevels<2>;
+  auto fail = [&](hipError_t e, const char* what) {
+    int r = hip_fail(e, what, __FILE__, __LINE__);
+    nbody_octree_destroy(t);
+    return r;
+  };
+#define NB_ALLOC(ptr, bytes)                                              \
+  do {                                                                    \
+    hipError_t e_ = hipMalloc(reinterpret_cast<void**>(&(ptr)), (bytes)); \
+    if (e_ != hipSuccess) return fail(e_, "hipMalloc(" #ptr ")");         \
+  } while (0)
+  NB_ALLOC(t->root, t->tsz * (dim + 1));
+  NB_ALLOC(t->partials, t->tsz * 2 * t->bounds_blocks);
+  NB_ALLOC(t->keys[0], sizeof(uint64_t) * size_t(n));
+  NB_ALLOC(t->keys[1], sizeof(uint64_t) * size_t(n));
+  NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
+  NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
+  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(radix_sort_blocks(n)) + 1));
+  NB_ALLOC(t->first_child, sizeof(uint32_t) * size_t(t->capacity));
+  NB_ALLOC(t->parent, sizeof(uint32_t) * size_t(t->max_cells));
+  NB_ALLOC(t->mono, t->tsz * 4 * size_t(t->capacity));
+  NB_ALLOC(t->cells, sizeof(ot_cell) * size_t(t->max_cells));
+  NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 3));
+#undef NB_ALLOC
+  *out = t;
+  return NBODY_OK;
+}
+
+extern "C" void nbody_octree_destroy(nbody_octree* t) {
+  if (!t) return;
+  (void)hipFree(t->root);
+  (void)hipFree(t->partials);
+  (void)hipFree(t->keys[0]);
+  (void)hipFree(t->keys[1]);
+  (void)hipFree(t->idx[0]);
+  (void)hipFree(t->idx[1]);
+  (void)hipFree(t->hist);
+  (void)hipFree(t->first_child);
+  (void)hipFree(t->parent);
+  (void)hipFree(t->mono);
+  (void)hipFree(t->cells);
+  (void)hipFree(t->lvl_count);
+  (void)hipFree(t->counters);
+  delete t;
+}
+
+extern "C" int nbody_octree_clear(nbody_octree* t, void* stream) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  (void)stream;  // every node the build allocates is fully rewritten by it: nothing to reset but the phase flags
+  t->inserted  = false;
+  t->have_tree = false;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s, void* stream) {
+  if (int r = ot_check(t, s)) return r;
+  int r = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return ot_bounds_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->have_bounds = true;
+  return r;
+}
+
+extern "C" int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* stream) {
+  if (int r = ot_check(t, s)) return r;
+  if (!t->have_bounds) {
+    set_error("nbody_octree_insert before nbody_octree_compute_bounds");
+    return NBODY_ERR_STATE;
+  }
+  int r = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return ot_insert_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->inserted = true;
+  return r;
+}
+
+extern "C" int nbody_octree_compute_tree(nbody_octree* t, void* stream) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (!t->inserted) {
+    set_error("nbody_octree_compute_tree before nbody_octree_insert");
+    return NBODY_ERR_STATE;
+  }
+  int r = dispatch(t->dtype, t->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return ot_tree_run<typename TG::type, TG::dim>(t, as_stream(stream));
+  });
+  if (r == NBODY_OK) t->have_tree = true;
+  return r;
+}
+
+extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream) {
+  if (int r = ot_check(t, s)) return r;
+  if (!t->have_tree) {
+    set_error("nbody_octree_compute_force before nbody_octree_compute_tree");
+    return NBODY_ERR_STATE;
+  }
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return ot_force_run<typename TG::type, TG::dim>(t, s, theta, as_stream(stream));
+  });
+}
+
+extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 2 * size_t(t->n)));
+  t->counters_on = on != 0;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, void* stream) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (!t->inserted) {
+    set_error("nbody_octree_info before nbody_octree_insert");
+    return NBODY_ERR_STATE;
+  }
+  hipStream_t st = as_stream(stream);
+  const int maxl = t->dim == 3 ? kMaxLevels<3> : kMaxLevels<2>;
+  uint32_t lv[40];
+  NB_HIP(hipMemcpyAsync(lv, t->lvl_count, sizeof(uint32_t) * (maxl + 3), hipMemcpyDeviceToHost, st));
+  char rec[32];
+  NB_HIP(hipMemcpyAsync(rec, t->mono, t->tsz * 4, hipMemcpyDeviceToHost, st));
+  NB_HIP(hipStreamSynchronize(st));
+  const uint32_t flags = lv[maxl + 2];
+  if (flags & kFlagDepth) {
+    set_error("octree depth limit: at least two bodies share all %d key levels (closer than root_side/2^%d in every coordinate)",
+              maxl, maxl);
+    return NBODY_ERR_STATE;
+  }
+  if (flags & kFlagCapacity) {
+    set_error("octree node pool exhausted (capacity %u nodes = System::max_tree_node_size)", t->capacity);
+    return NBODY_ERR_STATE;
+  }
+  uint64_t cells = 0;
+  for (int l = 0; l <= maxl; ++l) cells += lv[l];
+  if (tree_size) *tree_size = uint32_t(1 + cells * (1u << t->dim));  // next_free_child_group (src/octree.h:152)
+  if (root_mass) memcpy(root_mass, rec + 3 * t->tsz, t->tsz);         // m[0].mass()
+  return NBODY_OK;
+}
+
+extern "C" int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream) {
+  NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
+  NB_ARG(t->counters != nullptr, "counters were never enabled");
+  NB_ARG(bytes == sizeof(uint32_t) * 2 * size_t(t->n), "expected %zu bytes", sizeof(uint32_t) * 2 * size_t(t->n));
+  NB_HIP(hipMemcpyAsync(host_out, t->counters, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+  NB_HIP(hipStreamSynchronize(as_stream(stream)));
+  return NBODY_OK;
+}

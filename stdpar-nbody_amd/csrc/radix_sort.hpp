@@ -1,0 +1,155 @@
+// Stable LSD radix sort of (u64 key, u32 index) pairs, 8 bits per pass — shared by the Hilbert BVH (K6, replaces
+// std::sort at src/bvh.h:55-94) and the octree build.  Per pass: per-block digit histogram, per-digit row scan,
+// stable scatter (wave match-any ranking; the 256-digit base scan is folded into the scatter kernel).
+// Kernels are `static` so both translation units can include this header.
+#pragma once
+#include "common.hpp"
+
+namespace nbody {
+
+constexpr int kSortB = 256;
+constexpr int kSortIPT  = 8;  // keys per lane
+constexpr int kSortTile = kSortB * kSortIPT;  // 2048 keys per block; wave w owns keys [w*512, w*512+512)
+
+static __global__ __launch_bounds__(kSortB) void radix_hist_kernel(const uint64_t* __restrict__ keys, uint32_t n, int shift,
+                                                        uint32_t* __restrict__ hist, uint32_t nblk) {
+  __shared__ uint32_t cnt[256];
+  cnt[threadIdx.x] = 0;
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < kSortIPT; ++q) {
+    uint64_t i = uint64_t(blockIdx.x) * kSortTile + q * kSortB + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  hist[uint64_t(threadIdx.x) * nblk + blockIdx.x] = cnt[threadIdx.x];
+}
+
+// Exclusive scan of one digit's row hist[d][0..nblk) (one block per digit, coalesced) + the digit's total.
+// The scan ACROSS digits (256 totals) is folded into the scatter kernel, so a pass has no serial kernel.
+static __global__ __launch_bounds__(kSortB) void radix_scan_rows_kernel(uint32_t* __restrict__ hist, uint32_t nblk,
+                                                             uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wsum[kSortB / 64];
+  __shared__ uint32_t carry;
+  uint32_t* row  = hist + uint64_t(blockIdx.x) * nblk;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblk; base += kSortB) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblk ? row[i] : 0u;
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (i < nblk) row[i] = pre + inc - v;
+    __syncthreads();
+    if (threadIdx.x == kSortB - 1) carry = pre + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
+                                                           uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                           uint32_t n, int shift, const uint32_t* __restrict__ hist,
+                                                           const uint32_t* __restrict__ totals, uint32_t nblk) {
+  __shared__ uint32_t wcnt[kSortB / 64][256];
+  __shared__ uint32_t dbase[256];  // exclusive scan of the 256 digit totals
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int q = threadIdx.x; q < (kSortB / 64) * 256; q += kSortB) (&wcnt[0][0])[q] = 0;
+  __syncthreads();
+
+  uint64_t key[kSortIPT];
+  uint32_t pay[kSortIPT], rank[kSortIPT];
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int s = 0; s < kSortIPT; ++s) {
+    uint64_t i       = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
+    const bool valid = i < n;
+    key[s]           = valid ? keys_in[i] : 0ull;
+    pay[s]           = valid ? (idx_in ? idx_in[i] : uint32_t(i)) : 0u;
+    const uint32_t d = uint32_t(key[s] >> shift) & 255u;
+    // lanes of this strip holding the same digit
+    uint64_t same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit      = (d >> b) & 1u;
+      const uint64_t vote = __ballot(valid && bit);
+      same &= bit ? vote : ~vote;
+    }
+    const uint32_t before = __popcll(same & lt_mask);
+    const uint32_t base   = wcnt[wave][d];
+    rank[s]               = base + before;
+    __builtin_amdgcn_wave_barrier();
+    if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
+    __builtin_amdgcn_wave_barrier();
+  }
+  {  // digit = threadIdx.x: exclusive scan of totals[0..255]; within a wave here, wave offsets after the barrier
+    const uint32_t v = totals[threadIdx.x];
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    dbase[threadIdx.x] = inc - v;
+  }
+  __syncthreads();
+  // digit = threadIdx.x: turn per-wave counts into global bases
+  {
+    uint32_t woff = 0;
+    for (int w = 0; w < wave; ++w) woff += dbase[w * 64 + 63] + totals[w * 64 + 63];  // totals of the earlier 64-digit groups
+    uint32_t run = woff + dbase[threadIdx.x] + hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
+#pragma unroll
+    for (int w = 0; w < kSortB / 64; ++w) {
+      uint32_t cw          = wcnt[w][threadIdx.x];
+      wcnt[w][threadIdx.x] = run;
+      run += cw;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < kSortIPT; ++s) {
+    uint64_t i = uint64_t(blockIdx.x) * kSortTile + wave * (64 * kSortIPT) + s * 64 + lane;
+    if (i < n) {
+      const uint32_t d   = uint32_t(key[s] >> shift) & 255u;
+      const uint32_t pos = wcnt[wave][d] + rank[s];
+      keys_out[pos]      = key[s];
+      idx_out[pos]       = pay[s];
+    }
+  }
+}
+
+
+// hist needs 256 * (nblk + 1) u32, nblk = radix_sort_blocks(n).  Sorts by key bits [0, key_bits): the pairs start in
+// (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.
+inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+
+inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int key_bits, uint32_t* hist, hipStream_t st,
+                            int* final_buf) {
+  const uint32_t nblk    = radix_sort_blocks(n);
+  int cur                = 0;
+  const uint32_t* idx_in = nullptr;  // first pass: payload = position
+  for (int shift = 0; shift < key_bits; shift += 8) {
+    hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], n, shift, hist, nblk);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kSortB), 0, st, hist, nblk, hist + 256u * size_t(nblk));
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1], idx[cur ^ 1], n,
+                       shift, hist, hist + 256u * size_t(nblk), nblk);
+    NB_HIP(hipGetLastError());
+    cur ^= 1;
+    idx_in = idx[cur];
+  }
+  *final_buf = cur;
+  return NBODY_OK;
+}
+
+}  // namespace nbody

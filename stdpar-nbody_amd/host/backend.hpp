@@ -29,6 +29,7 @@ class Device {
     push();
   }
   ~Device() {
+    if (octree_) nbody_octree_destroy(octree_);
     if (tree_) nbody_bvh_destroy(tree_);
     nbody_destroy(ctx_);
   }
@@ -84,6 +85,25 @@ class Device {
   void bvh_compute_force(double theta) {
     backend_check(nbody_bvh_compute_force(tree_, &view_, theta, stream()), "nbody_bvh_compute_force");
   }
+  // octree phases (src/octree.h)
+  void octree_alloc() {
+    if (!octree_) backend_check(nbody_octree_create(&octree_, dtype, D, host_.n), "nbody_octree_create");
+  }
+  void octree_clear() { backend_check(nbody_octree_clear(octree_, stream()), "nbody_octree_clear"); }
+  void octree_compute_bounds() { backend_check(nbody_octree_compute_bounds(octree_, &view_, stream()), "nbody_octree_compute_bounds"); }
+  void octree_insert() { backend_check(nbody_octree_insert(octree_, &view_, stream()), "nbody_octree_insert"); }
+  void octree_compute_tree() { backend_check(nbody_octree_compute_tree(octree_, stream()), "nbody_octree_compute_tree"); }
+  void octree_compute_force(double theta) {
+    backend_check(nbody_octree_compute_force(octree_, &view_, theta, stream()), "nbody_octree_compute_force");
+  }
+  // {tree size, total mass}; also where device-side build errors (depth limit, node pool) surface
+  std::pair<std::uint32_t, T> octree_info() {
+    std::uint32_t size = 0;
+    T mass{};
+    backend_check(nbody_octree_info(octree_, &size, &mass, stream()), "nbody_octree_info");
+    return {size, mass};
+  }
+
   // mass of the root monopole, for --print-info (src/bvh.h:377)
   T bvh_total_mass() {
     std::vector<T> nodes(std::size_t(nbody_bvh_nnodes(tree_)) * (D + 1));
@@ -95,6 +115,7 @@ class Device {
   System<T, D>& host_;
   nbody_ctx* ctx_  = nullptr;
   nbody_bvh* tree_ = nullptr;
+  nbody_octree* octree_ = nullptr;
   nbody_state view_{};
 };
 

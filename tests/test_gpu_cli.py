@@ -70,8 +70,14 @@ def test_csv_rows():
     assert re.fullmatch(r"bvh,3,64,3,500(,\d+\.\d\d){7}", lines[-1])
     r = cli(3, ["-n", 100, "--csv-total", "--print-state", "--algorithm", "bvh"])
     assert r.returncode != 0  # abort(), as the reference (src/bvh.h:334-339)
-    r = cli(3, ["-n", 100, "--algorithm", "octree"])
-    assert r.returncode == 1 and "octree" in r.stderr
+    # octree is the DEFAULT algorithm (src/arguments.h:28): no --algorithm flag
+    r = cli(3, ["-n", 100, "-s", 2, "--precision", "double", "--workload", "galaxy", "--print-info", "--csv-detailed"])
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == ("algorithm,dim,precision,nsteps,nbodies,total [s],force [s],accel [s],clear [s],bbox [s],insert [s],"
+                        "multipoles [s],force approx [s]")
+    # same text as the reference for this input (oracle/_ref: "Tree size: 697 / 681", "Total mass:  11002.00000")
+    assert lines[1:6] == ["Tree init complete", "Tree size: 697", "Total mass:  11002.00000", "Tree size: 681", "Total mass:  11002.00000"]
+    assert re.fullmatch(r"octree,3,64,2,100(,\d+\.\d\d){8}", lines[6])
 
 
 def test_saved_frames_and_energy_vs_reference(oracle, golden_positions):

@@ -1,0 +1,134 @@
+"""GPU parity: octree Barnes-Hut (the reference's default --algorithm, src/octree.h) built without locks
+(path keys -> radix sort -> breadth-first split) vs the oracle's serial restatement of the reference's lock-based
+insertion.  Node numbering differs by construction; everything observable must not: tree size, root monopole
+(bit-exact), per-body visit counters (bit-exact: the opening test uses IEEE sqrt/divide) and the forces
+(tolerance: the accepted term uses a polished reciprocal)."""
+import numpy as np
+import pytest
+
+from conftest import DT
+
+pytestmark = pytest.mark.gpu
+
+FORCE_TOL = {0: 2e-5, 1: 1e-12}
+TRAJ_TOL = {0: 2e-3, 1: 1e-11}
+
+
+def maxrel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
+    cases = [("uniform", 1), ("uniform", 2), ("uniform", 3), ("galaxy", 10), ("uniform", 257), ("galaxy", 1000), ("uniform", 4099),
+             ("galaxy", 20000)]
+    if dim == 3:
+        cases.append(("plummer", 1000))
+    for wl, n in cases:
+        for theta in (0.0, 0.5, 1.0):
+            ref = oracle.build_model(dtype, dim, wl, n)
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+            dev.octree.enable_counters(True)
+            dev.octree_force(theta)
+            dev.sync()
+            size, mass = dev.octree.info(dev.stream)
+            ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+            assert size == osize, (wl, n, "tree size")
+            assert mass == omass, (wl, n, "root mass")
+            assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt), (wl, n, theta, "visit counters")
+            out = dev.download()
+            assert maxrel(out.a, ref.a) <= FORCE_TOL[dtype], (wl, n, theta)
+            for k in ("m", "x", "v"):  # unlike bvh, the octree does not permute the bodies
+                assert np.array_equal(getattr(out, k), getattr(ref, k))
+            dev.close()
+
+
+def test_octree_theta0_equals_all_pairs(nb):
+    """theta = 0 never approximates: the walk reaches every body leaf (README.md:122-129)."""
+    n = 3000
+    d1 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    d2 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    d1.all_pairs_force()
+    d2.octree_force(0.0)
+    # the octree term is m*d/(sqrt(r2)+eps)^3, all-pairs is m*d/(r2^1.5 + eps): equal to ~eps/r
+    assert maxrel(d2.download().a, d1.download().a) <= 1e-9
+
+
+def test_trajectories_vs_reference_fixtures(nb, golden_positions):
+    meta, data = golden_positions
+    ran = 0
+    for name, case in meta.items():
+        if case["algorithm"] != "octree":
+            continue
+        dtype = DT[case["precision"]]
+        ref = data[name + "__frames"]
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, case["dim"], case["workload"], case["n"]))
+        scale = np.abs(ref[0]).max()
+        k = 1
+        for step in range(1, case["steps"] + 1):
+            nb.run(dev, "octree", 1, case["theta"])
+            if step in case["frame_ids"]:
+                assert np.abs(dev.download().x - ref[k]).max() <= TRAJ_TOL[dtype] * scale, (name, step)
+                k += 1
+        dev.octree.info(dev.stream)
+        dev.close()
+        ran += 1
+    assert ran >= 30
+
+
+def test_octree_shard_windows_and_graph(nb):
+    n = 9000
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    dev.octree_force(0.5)
+    full = dev.download().a.copy()
+    hs = dev.download()
+    hs.a[:] = 0
+    dev.upload(hs)
+    for f, c in ((0, 1000), (1000, 4001), (5001, 3999)):
+        dev.octree.compute_force(dev.state(f, c), 0.5, dev.stream)
+    assert np.array_equal(dev.download().a, full)
+    # a recorded step replays to the same state as direct calls
+    d1 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    nb.run(d1, "octree", 3, 0.5)
+    d2 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    _ = d2.octree
+    g = nb.StepGraph(d2, lambda: (d2.octree_force(0.5), d2.accelerate_step()))
+    for _ in range(3):
+        g.launch()
+    d2.sync()
+    a, b = d1.download(), d2.download()
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.a, b.a)
+
+
+def test_octree_errors(nb):
+    hs = nb.HostSystem(1, 3, 4)
+    hs.m[:] = 1
+    hs.x[:] = [[0, 0, 0], [1, 1, 1], [1, 1, 1], [2, 0, 1]]  # two coincident bodies: the reference would split forever
+    hs.c, hs.dt = 1.0, 0.1
+    dev = nb.DeviceSystem.from_host(hs)
+    dev.octree_force(0.5)
+    dev.sync()
+    with pytest.raises(nb.NbodyError, match="depth limit"):
+        dev.octree.info(dev.stream)
+    d2 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "uniform", 50))
+    with pytest.raises(nb.NbodyError, match="before nbody_octree_compute_bounds"):
+        d2.octree.insert(d2.state(), d2.stream)
+    with pytest.raises(nb.NbodyError, match="before nbody_octree_compute_tree"):
+        d2.octree.compute_force(d2.state(), 0.5, d2.stream)
+
+
+def test_octree_full_size(nb, oracle):
+    """N = 1e6 galaxy, theta = 0.5 (the reference's tree benchmark size): whole force phase vs the oracle."""
+    n = 1000000
+    ref = oracle.build_model(1, 3, "galaxy", n)
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    dev.octree.enable_counters(True)
+    dev.octree_force(0.5)
+    dev.sync()
+    size, mass = dev.octree.info(dev.stream)
+    ocnt, osize, omass = oracle.octree_step_force(ref, 0.5, want_counts=True)
+    assert (size, mass) == (osize, omass)
+    assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt)
+    assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[1]

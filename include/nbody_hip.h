@@ -161,6 +161,9 @@ int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, voi
 /* Test/diagnostic: per-body {nodes examined, terms accumulated} u32[n][2] of the last compute_force. */
 int nbody_octree_enable_counters(nbody_octree* t, int on);
 int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream);
+/* Scheduling form of compute_force, as nbody_bvh_set_traversal: 0 = auto, 1 = one walk per lane, 2 = wave-cooperative
+ * sweep of the union of the 64 lanes' walks.  Results and counters are bitwise identical. */
+int nbody_octree_set_traversal(nbody_octree* t, int mode);
 
 /* ---- owning context (device mirrors of a host System), used by the C++ CLI host ------------------ */
 

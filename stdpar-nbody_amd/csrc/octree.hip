@@ -40,6 +40,20 @@ struct ot_cell {  // an internal cell waiting to be split: its node index and it
   uint32_t node, start, end;
 };
 
+// One tree node = one aligned record of 8 scalars (64 B f64 / 32 B f32): monopole (src/octree.h:55-56 `m`), the side of
+// its cell (the reference halves/doubles a running value while it walks, src/octree.h:245,257 — power-of-two scaling is
+// exact, so the stored value has the same bits), first child (src/octree.h:52) and the node the reference's walk reaches
+// after this node's whole subtree ("rope": next sibling, or the rope of the parent for a last sibling — the closed form
+// of next_node() + the backward steps, src/octree.h:63-71,250-259).
+template <typename T>
+struct alignas(8 * sizeof(T)) ot_node {
+  T p[3];
+  T m;
+  T side;
+  uint32_t fc, skip;
+};
+static_assert(sizeof(ot_node<double>) == 64 && sizeof(ot_node<float>) == 32, "one aligned record per node");
+
 template <typename T>
 __device__ __forceinline__ T ot_fmin(T a, T b) {
   if constexpr (sizeof(T) == 4) return __builtin_fminf(a, b);
@@ -142,31 +156,36 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
 
 // ---- breadth-first build --------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, uint32_t* __restrict__ first_child,
-                                     src_rec<T, D>* __restrict__ mono, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
+__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, const T* __restrict__ root,
+                                     ot_node<T>* __restrict__ nodes, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
                                      uint32_t* __restrict__ flags) {
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     flags[0] = 0;
-    if (n >= 2) {  // the root holds >= 2 bodies: it is the first cell to split
+    ot_node<T> r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.p[k] = T(0);
+    r.m    = T(0);
+    r.side = root[D];
+    r.fc   = kOtEmpty;
+    r.skip = kOtEmpty;  // the walk ends after the root's subtree
+    if (n >= 2) {       // the root holds >= 2 bodies: it is the first cell to split
       cells[0]     = ot_cell{0u, 0u, n};
       lvl_count[0] = 1;
     } else {  // a single body stays in the root (src/octree.h:140-145)
-      src_rec<T, D> r;
 #pragma unroll
-      for (int k = 0; k < 3; ++k) r.p[k] = k < D ? x[k] : T(0);
-      r.m            = m[0];
-      mono[0]        = r;
-      first_child[0] = kOtBody;
+      for (int k = 0; k < D; ++k) r.p[k] = x[k];
+      r.m  = m[0];
+      r.fc = kOtBody;
     }
+    nodes[0] = r;
   }
 }
 
 template <typename T, int D>
 __global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
                                                              const uint32_t* __restrict__ sidx, const T* __restrict__ m,
-                                                             const T* __restrict__ x, uint32_t* __restrict__ first_child,
-                                                             uint32_t* __restrict__ parent, src_rec<T, D>* __restrict__ mono,
+                                                             const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
                                                              ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
                                                              uint32_t* __restrict__ flags, uint32_t capacity, uint32_t max_cells) {
   constexpr uint32_t NCH = 1u << D;
@@ -179,17 +198,16 @@ __global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const ui
   const ot_cell cell  = cells[rank];
   const uint32_t fc   = 1u + rank * NCH;  // its sibling group (the reference's bump allocator hands out the same shape)
   if (level >= kMaxLevels<D>) {           // >= 2 bodies share every key digit: deeper than the keys resolve
-    atomicOr(flags, kFlagDepth);
-    first_child[cell.node] = kOtEmpty;
+    atomicOr(flags, kFlagDepth);  // the node stays an (empty) leaf; nbody_octree_info reports the error
     return;
   }
   if (fc + NCH > capacity) {
     atomicOr(flags, kFlagCapacity);
-    first_child[cell.node] = kOtEmpty;
     return;
   }
-  first_child[cell.node] = fc;
-  parent[rank]           = cell.node;  // parent[sg(fc)], sg(fc) = (fc - 1) / 2^D = rank
+  const T child_side       = nodes[cell.node].side / T(2);  // src/octree.h:245
+  const uint32_t cell_skip = nodes[cell.node].skip;
+  nodes[cell.node].fc      = fc;
 
   // child ranges: bodies are sorted by key, so the bodies of hyperant c are those whose digit at this level is c
   const int shift = D * (kMaxLevels<D> - 1 - level);
@@ -211,37 +229,33 @@ __global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const ui
   for (uint32_t c = 0; c < NCH; ++c) {
     const uint32_t cnt = bound[c + 1] - bound[c];
     const uint32_t ci  = fc + c;
-    src_rec<T, D> r;
+    ot_node<T> r;
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.p[q] = T(0);
-    r.m = T(0);
-    if (cnt == 0) {  // empty leaf: zero monopole (src/octree.h:77-83)
-      first_child[ci] = kOtEmpty;
-      mono[ci]        = r;
-    } else if (cnt == 1) {  // leaf with one body (src/octree.h:140-145, :163-165)
+    r.m    = T(0);  // empty leaf: zero monopole (src/octree.h:77-83); a cell's monopole is filled in by the multipole pass
+    r.side = child_side;
+    r.fc   = kOtEmpty;
+    r.skip = c + 1 < NCH ? ci + 1u : cell_skip;  // next sibling, else wherever the walk goes after the parent
+    if (cnt == 1) {                              // leaf with one body (src/octree.h:140-145, :163-165)
       const uint64_t b = sidx[bound[c]];
 #pragma unroll
       for (int q = 0; q < D; ++q) r.p[q] = x[b * D + q];
-      r.m             = m[b];
-      first_child[ci] = kOtBody;
-      mono[ci]        = r;
-    } else {  // >= 2 bodies: split it on the next level
+      r.m  = m[b];
+      r.fc = kOtBody;
+    }
+    nodes[ci] = r;
+    if (cnt >= 2) {  // split it on the next level (which sets its fc)
       const uint32_t pos = atomicAdd(&lvl_count[level + 1], 1u);
-      if (next_base + pos < max_cells) {
-        cells[next_base + pos] = ot_cell{ci, bound[c], bound[c + 1]};
-      } else {
-        atomicOr(flags, kFlagCapacity);
-        first_child[ci] = kOtEmpty;
-        mono[ci]        = r;
-      }
+      if (next_base + pos < max_cells) cells[next_base + pos] = ot_cell{ci, bound[c], bound[c + 1]};
+      else atomicOr(flags, kFlagCapacity);
     }
   }
 }
 
 // ---- multipoles (src/octree.h:205-216) ---------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, const uint32_t* __restrict__ first_child,
-                                                                 src_rec<T, D>* __restrict__ mono, const ot_cell* __restrict__ cells,
+__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_node<T>* __restrict__ nodes,
+                                                                 const ot_cell* __restrict__ cells,
                                                                  const uint32_t* __restrict__ lvl_count) {
 #pragma clang fp contract(off)
   constexpr uint32_t NCH = 1u << D;
@@ -251,22 +265,20 @@ __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, cons
   uint32_t base = 0;
   for (int j = 0; j < level; ++j) base += lvl_count[j];
   const uint32_t node = cells[base + k].node;
-  const uint32_t fc   = first_child[node];
+  const uint32_t fc   = nodes[node].fc;
   if (fc == kOtEmpty || fc == kOtBody) return;  // only after an overflow flag
   T mass = T(0), xx[D];
 #pragma unroll
   for (int q = 0; q < D; ++q) xx[q] = T(0);
   for (uint32_t c = 0; c < NCH; ++c) {  // child order; empty children add (0, 0)
-    const src_rec<T, D> ch = mono[fc + c];
-    mass += ch.m;
+    const T cm = nodes[fc + c].m;
+    mass += cm;
 #pragma unroll
-    for (int q = 0; q < D; ++q) xx[q] += ch.m * ch.p[q];
+    for (int q = 0; q < D; ++q) xx[q] += cm * nodes[fc + c].p[q];
   }
-  src_rec<T, D> r;
 #pragma unroll
-  for (int q = 0; q < 3; ++q) r.p[q] = q < D ? xx[q < D ? q : 0] / mass : T(0);
-  r.m        = mass;
-  mono[node] = r;
+  for (int q = 0; q < D; ++q) nodes[node].p[q] = xx[q] / mass;
+  nodes[node].m = mass;
 }
 
 // ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------
@@ -281,78 +293,109 @@ __device__ __forceinline__ T ot_sqrt(T v) {
   else return __builtin_sqrt(v);
 }
 template <typename T>
-__device__ __forceinline__ T ot_recip(T d) {  // 1/d to ~2e-15 (f64: seed + one Newton step) / ~1 ulp (f32)
+__device__ __forceinline__ T ot_rsq(T v) {  // hardware seed: 1 ulp (f32) / ~2^-24 (f64, profiles/r01_valu_rates_microbench.txt)
+  if constexpr (sizeof(T) == 4) return __builtin_amdgcn_rsqf(v);
+  else return __builtin_amdgcn_rsq(v);
+}
+template <typename T>
+__device__ __forceinline__ T ot_recip(T d) {  // 1/d to ~2e-16 relative (seed + one Newton step)
   if constexpr (sizeof(T) == 4) {
-    return __builtin_amdgcn_rcpf(d);
+    const float z0 = __builtin_amdgcn_rcpf(d);
+    return __builtin_fmaf(z0, __builtin_fmaf(-d, z0, 1.0f), z0);
   } else {
     const double z0 = __builtin_amdgcn_rcp(d);
     return __builtin_fma(z0, __builtin_fma(-d, z0, 1.0), z0);
   }
 }
 
+template <typename T>
+struct ot_consts {
+  static constexpr T eps  = sizeof(T) == 4 ? T(FLT_EPSILON) : T(DBL_EPSILON);
+  static constexpr T tiny = sizeof(T) == 4 ? T(1e-30f) : T(1e-300);  // sqrt(tiny) + eps == eps: coincident points unchanged
+};
+template <typename T>
+struct ot_theta {  // theta and the two guard values of the quick opening test
+  T exact, lo, hi;
+  __device__ explicit ot_theta(T theta) : exact(theta), lo(theta * (T(1) - T(1) / T(65536))), hi(theta * (T(1) + T(1) / T(65536))) {}
+};
+
+// dist2(x, xj) summed exactly as the reference does (src/vec.h:232-241): the opening decision depends on its bits.
+template <typename T, int D>
+__device__ __forceinline__ T ot_dist2(const T (&di)[D]) {
+#pragma clang fp contract(off)
+  T d2 = T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) d2 = d2 + di[k] * di[k];
+  return d2;
+}
+
+// Opening test `side / (sqrt(d2) + eps) < theta` (src/octree.h:243, src/vec.h:243-246).  The reference's decision is
+// reproduced bit-for-bit: q = side * rsq(d2) brackets the exact quotient to ~2^-23, so a lane whose q is outside
+// theta*(1 -+ 2^-16) is decided by it; if any lane that `need`s a decision is inside the band (or holds a NaN/inf), the
+// wave evaluates the IEEE sqrt and divide.  y0 = rsq(max(d2, tiny)).
+template <typename T>
+__device__ __forceinline__ bool ot_accept(bool need, T side, T d2, T y0, const ot_theta<T>& th) {
+  const T q  = side * y0;                                             // >= side / (sqrt(d2) + eps), up to the seed error
+  const T ql = __builtin_elementwise_fma(-q, ot_consts<T>::eps * y0, q);  // <= it: 1/(1 + eps/s) >= 1 - eps/s
+  const bool sure_take = q < th.lo, sure_open = ql > th.hi;
+  bool take = sure_take;
+  if (__ballot(need && !sure_take && !sure_open) != 0ull) {
+#pragma clang fp contract(off)
+    take = side / (ot_sqrt(d2) + ot_consts<T>::eps) < th.exact;
+  }
+  return take;
+}
+
+// a += mj * (xj - x) / dx^3, dx = sqrt(d2) + eps (src/octree.h:240-241), for the lanes in `on`; tolerance parity: sqrt from
+// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  di = x - xj.  The body's own leaf and
+// empty leaves add exactly 0 (di == 0 or mj == 0) because dx^3 >= eps^3 keeps the weight finite.
+template <typename T, int D>
+__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di)[D], T mj, T d2a, T y0) {
+#pragma clang fp contract(off)
+  const T t  = d2a * y0;
+  const T e  = __builtin_elementwise_fma(-t, y0, T(1));
+  const T sq = __builtin_elementwise_fma(T(0.5) * t, e, t);
+  const T dx = sq + ot_consts<T>::eps;
+  T w        = mj * ot_recip((dx * dx) * dx);
+  w          = on ? -w : T(0);
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, di[k], acc[k]);
+}
+
+// Per-lane walks: lane = body (in key order), the reference's loop with the ropes in place of its backward steps.
+// Lanes drift apart in the tree, so every step is a divergent 64-line gather; the faster form while few waves are in flight.
 template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_kernel(const uint32_t* __restrict__ first_child, const uint32_t* __restrict__ parent,
-                                                      const src_rec<T, D>* __restrict__ mono, const uint32_t* __restrict__ sidx,
-                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                                      uint32_t count, T theta, const T* __restrict__ root,
-                                                      uint32_t* __restrict__ counters) {
-  constexpr uint32_t NCH = 1u << D;
-  constexpr T eps        = sizeof(T) == 4 ? T(FLT_EPSILON) : T(DBL_EPSILON);
-  // lanes take bodies in key order (spatially adjacent bodies walk nearly the same nodes); XCD-contiguous blocks
-  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+__device__ __forceinline__ void ot_walk_lanes(uint32_t t, const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                              const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                              uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
   if (t >= sz) return;
   const uint32_t body = sidx[t];
   if (body < first || body - first >= count) return;
+  const ot_theta<T> th(theta);
   T xi[D], acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
     xi[k]  = x[uint64_t(body) * D + k];
     acc[k] = T(0);
   }
-  uint32_t idx = 0;
-  T side       = root[D];
-  bool fwd     = true;
-  uint32_t c_nodes = 0, c_terms = 0;
-  uint32_t guard = 0;  // a well-formed tree is left after < 2*capacity steps; never spin on a damaged one
-  while (idx != kOtEmpty && ++guard != 0xfffffff0u) {
-    // next_node (src/octree.h:63-71): next sibling, or the parent after the last sibling
-    uint32_t next;
-    if (idx == 0) {
-      next = kOtEmpty;
-    } else {
-      const uint32_t sg = (idx - 1u) / NCH, cp = (idx - 1u) % NCH;
-      next = cp == NCH - 1u ? parent[sg] : idx + 1u;
-    }
-    if (fwd) {  // arrived from a parent or a sibling: examine the node
-      const src_rec<T, D> mj = mono[idx];
-      const uint32_t fc      = first_child[idx];
-      T dx;
-      bool take;
-      {
-#pragma clang fp contract(off)
-        T d2 = T(0);  // dist(x, xj) = sqrt(dist2) + eps, src/vec.h:232-246
+  uint32_t idx = 0, c_nodes = 0, c_terms = 0;
+  uint32_t guard = capacity;  // a well-formed tree is left after <= capacity steps; never spin on a damaged one
+  while (idx != kOtEmpty && guard-- != 0u) {
+    const ot_node<T> nd = nodes[idx];
+    T di[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-          const T di = xi[k] - mj.p[k];
-          d2         = d2 + di * di;
-        }
-        dx   = ot_sqrt(d2) + eps;
-        take = fc == kOtEmpty || fc == kOtBody || side / dx < theta;  // IEEE divide: decisions are the reference's
-      }
-      if (COUNT) ++c_nodes;
-      if (take) {  // a += mj * (xj - x) / (dx*dx*dx); the body's own leaf and empty leaves add exactly 0
-        const T w = mj.m * ot_recip((dx * dx) * dx);
-#pragma unroll
-        for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, mj.p[k] - xi[k], acc[k]);
-        if (COUNT) ++c_terms;
-      } else {  // visit the children
-        next = fc;
-        side = side / T(2);
-      }
+    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    const T d2      = ot_dist2<T, D>(di);
+    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
+    const T y0      = ot_rsq(d2a);
+    const bool leaf = nd.fc >= kOtBody;  // kOtBody or kOtEmpty
+    const bool take = leaf || ot_accept<T>(!leaf, nd.side, d2, y0, th);
+    if (COUNT) {
+      ++c_nodes;
+      c_terms += take;
     }
-    fwd  = next > idx;  // children are allocated after their parent
-    side = fwd ? side : side * T(2);
-    idx  = next;
+    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2a, y0);
+    idx = take ? nd.skip : nd.fc;
   }
 #pragma unroll
   for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
@@ -360,6 +403,79 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const uint32_t* __restrict
     counters[uint64_t(body) * 2 + 0] = c_nodes;
     counters[uint64_t(body) * 2 + 1] = c_terms;
   }
+}
+
+// Wave-cooperative sweep: the 64 bodies of a wave (neighbours in key order) walk nearly the same nodes, so the wave walks the
+// UNION of their walks once, in the same depth-first order: the node is wave-uniform (one scalar load of its record), a
+// lane's state is the node it waits for — exactly the `idx` of its own walk — and it takes part when the sweep arrives
+// there.  The sweep descends if any participating lane opens the node, otherwise follows the rope; a lane that accepted a
+// node the sweep descends into simply waits at the rope's target, which the sweep reaches when it leaves that subtree.
+// Every lane performs its own walk's tests and additions in its own order: results are bitwise those of ot_force_kernel.
+template <typename T, int D, bool COUNT>
+__device__ __forceinline__ void ot_walk_wave(uint32_t t, const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                             const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                             uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
+  const uint32_t body = t < sz ? sidx[t] : kOtEmpty;
+  const bool valid    = t < sz && body >= first && body - first < count;
+  if (__ballot(valid) == 0ull) return;
+  const ot_theta<T> th(theta);
+  T xi[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
+    acc[k] = T(0);
+  }
+  uint32_t wait = valid ? 0u : kOtEmpty;  // lanes outside the shard never take part
+  uint32_t idx  = 0;                      // wave-uniform
+  uint32_t c_nodes = 0, c_terms = 0;
+  uint32_t guard = capacity;
+  while (idx != kOtEmpty && guard-- != 0u) {
+    const ot_node<T> nd = nodes[idx];  // wave-uniform address: scalar loads
+    const bool active   = wait == idx;
+    T di[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    const T d2      = ot_dist2<T, D>(di);
+    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
+    const T y0      = ot_rsq(d2a);
+    const bool leaf = nd.fc >= kOtBody;  // wave-uniform
+    const bool take = leaf || ot_accept<T>(active, nd.side, d2, y0, th);
+    const bool acc_l = active && take, open_l = active && !take;
+    if (COUNT) {
+      c_nodes += active;
+      c_terms += acc_l;
+    }
+    if (__ballot(acc_l) != 0ull) ot_accumulate<T, D>(acc_l, acc, di, nd.m, d2a, y0);
+    wait = active ? (take ? nd.skip : nd.fc) : wait;
+    idx  = __builtin_amdgcn_readfirstlane(__ballot(open_l) != 0ull ? nd.fc : nd.skip);
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(body) * 2 + 0] = c_nodes;
+      counters[uint64_t(body) * 2 + 1] = c_terms;
+    }
+  }
+}
+
+// Mixing the forms on a CU (k of every 8 blocks sweeping, so that the walks load the texture-address unit and the sweeps the
+// VALU) was measured and does not help: 5.05-5.3 ms for every k at N = 10^6 — a sweeping wave's 3.6k dependent steps are
+// then the critical path.
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                                      uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
+  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  ot_walk_lanes<T, D, COUNT>(t, nodes, sidx, x, a, c, sz, first, count, theta, capacity, counters);
+}
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_wave_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                                           const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
+                                                           uint32_t first, uint32_t count, T theta, uint32_t capacity,
+                                                           uint32_t* __restrict__ counters) {
+  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  ot_walk_wave<T, D, COUNT>(t, nodes, sidx, x, a, c, sz, first, count, theta, capacity, counters);
 }
 
 }  // namespace nbody
@@ -374,13 +490,12 @@ struct nbody_octree {
   uint64_t* keys[2] = {nullptr, nullptr};
   uint32_t* idx[2]  = {nullptr, nullptr};
   uint32_t* hist   = nullptr;
-  uint32_t* first_child = nullptr;
-  uint32_t* parent = nullptr;
-  void* mono       = nullptr;  // src_rec<T,D>[capacity]
+  void* nodes      = nullptr;  // ot_node<T>[capacity]
   nbody::ot_cell* cells = nullptr;
   uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
   uint32_t* counters = nullptr;
   int sorted_buf   = 0;
+  int traversal    = 0;  // 0 auto, 1 per-lane walks, 2 wave-cooperative sweep
   bool counters_on = false, have_bounds = false, inserted = false, have_tree = false;
 };
 
@@ -411,7 +526,7 @@ template <typename T, int D>
 static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
   const uint32_t n       = s->sz;
-  auto* mono             = static_cast<src_rec<T, D>*>(t->mono);
+  auto* nodes            = static_cast<ot_node<T>*>(t->nodes);
   hipLaunchKernelGGL((ot_keys_kernel<T, D>), dim3((n + kOB - 1) / kOB), dim3(kOB), 0, st, static_cast<const T*>(s->x), n,
                      static_cast<const T*>(t->root), t->keys[0]);
   NB_HIP(hipGetLastError());
@@ -420,14 +535,14 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   t->sorted_buf = fin;
   uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), t->first_child, mono, t->cells, t->lvl_count, flags);
+                     static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells, t->lvl_count, flags);
   NB_HIP(hipGetLastError());
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
   for (int l = 0; l <= kMaxLevels<D>; ++l) {
     const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
     hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
-                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), t->first_child,
-                       t->parent, mono, t->cells, t->lvl_count, flags, t->capacity, t->max_cells);
+                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), nodes, t->cells,
+                       t->lvl_count, flags, t->capacity, t->max_cells);
     NB_HIP(hipGetLastError());
     if (width < (uint64_t(1) << 40)) width *= NCH;
   }
@@ -437,13 +552,13 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
 template <typename T, int D>
 static int ot_tree_run(nbody_octree* t, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
-  auto* mono             = static_cast<src_rec<T, D>*>(t->mono);
+  auto* nodes            = static_cast<ot_node<T>*>(t->nodes);
   for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
     uint64_t width = 1;
     for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
     const uint64_t cap_l = width < uint64_t(t->n / 2 + 1) ? width : uint64_t(t->n / 2 + 1);
     hipLaunchKernelGGL((ot_multipole_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
-                       t->first_child, mono, t->cells, t->lvl_count);
+                       nodes, t->cells, t->lvl_count);
     NB_HIP(hipGetLastError());
   }
   return NBODY_OK;
@@ -453,13 +568,22 @@ template <typename T, int D>
 static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hipStream_t st) {
   if (s->count == 0) return NBODY_OK;
   const uint32_t blocks = (s->sz + 63) / 64;
-  auto* mono            = static_cast<const src_rec<T, D>*>(t->mono);
-#define NB_OT_ARGS                                                                                                              \
-  t->first_child, t->parent, mono, t->idx[t->sorted_buf], static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), \
-   s->sz, s->first, s->count, static_cast<T>(theta), static_cast<const T*>(t->root), t->counters
-  if (t->counters_on) hipLaunchKernelGGL((ot_force_kernel<T, D, true>), dim3(blocks), dim3(64), 0, st, NB_OT_ARGS);
-  else hipLaunchKernelGGL((ot_force_kernel<T, D, false>), dim3(blocks), dim3(64), 0, st, NB_OT_ARGS);
-#undef NB_OT_ARGS
+  auto* nodes           = static_cast<const ot_node<T>*>(t->nodes);
+  // auto: the per-lane walks are the faster form in f64 at every size measured (5.1 vs 5.4 ms at N = 10^6; 0.54 vs 1.2 ms
+  // at 10^5); in f32 the sweep wins from ~600k bodies (3.35 vs 3.61 ms at 10^6)   [tools/time_octree.py, one MI355X]
+  const bool wave = t->traversal == 2 || (t->traversal == 0 && sizeof(T) == 4 && s->count >= 600000u);
+#define NB_OT_LAUNCH(KERN, CNT)                                                                                                  \
+  hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf], static_cast<const T*>(s->x), \
+                     static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, static_cast<T>(theta), t->capacity, \
+                     t->counters)
+  if (wave) {
+    if (t->counters_on) NB_OT_LAUNCH(ot_force_wave_kernel, true);
+    else NB_OT_LAUNCH(ot_force_wave_kernel, false);
+  } else {
+    if (t->counters_on) NB_OT_LAUNCH(ot_force_kernel, true);
+    else NB_OT_LAUNCH(ot_force_kernel, false);
+  }
+#undef NB_OT_LAUNCH
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -501,9 +625,7 @@ extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint3
   NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(radix_sort_blocks(n)) + 1));
-  NB_ALLOC(t->first_child, sizeof(uint32_t) * size_t(t->capacity));
-  NB_ALLOC(t->parent, sizeof(uint32_t) * size_t(t->max_cells));
-  NB_ALLOC(t->mono, t->tsz * 4 * size_t(t->capacity));
+  NB_ALLOC(t->nodes, t->tsz * 8 * size_t(t->capacity));
   NB_ALLOC(t->cells, sizeof(ot_cell) * size_t(t->max_cells));
   NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 3));
 #undef NB_ALLOC
@@ -520,9 +642,7 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
   (void)hipFree(t->idx[0]);
   (void)hipFree(t->idx[1]);
   (void)hipFree(t->hist);
-  (void)hipFree(t->first_child);
-  (void)hipFree(t->parent);
-  (void)hipFree(t->mono);
+  (void)hipFree(t->nodes);
   (void)hipFree(t->cells);
   (void)hipFree(t->lvl_count);
   (void)hipFree(t->counters);
@@ -587,6 +707,13 @@ extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s,
   });
 }
 
+extern "C" int nbody_octree_set_traversal(nbody_octree* t, int mode) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  NB_ARG(mode >= 0 && mode <= 2, "traversal mode must be 0 (auto), 1 (per-lane) or 2 (wave-cooperative), got %d", mode);
+  t->traversal = mode;
+  return NBODY_OK;
+}
+
 extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
   if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 2 * size_t(t->n)));
@@ -605,7 +732,7 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
   uint32_t lv[40];
   NB_HIP(hipMemcpyAsync(lv, t->lvl_count, sizeof(uint32_t) * (maxl + 3), hipMemcpyDeviceToHost, st));
   char rec[32];
-  NB_HIP(hipMemcpyAsync(rec, t->mono, t->tsz * 4, hipMemcpyDeviceToHost, st));
+  NB_HIP(hipMemcpyAsync(rec, t->nodes, t->tsz * 4, hipMemcpyDeviceToHost, st));
   NB_HIP(hipStreamSynchronize(st));
   const uint32_t flags = lv[maxl + 2];
   if (flags & kFlagDepth) {

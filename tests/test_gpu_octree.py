@@ -31,6 +31,7 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             ref = oracle.build_model(dtype, dim, wl, n)
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.octree.enable_counters(True)
+            dev.octree.set_traversal(1 + (n + int(theta * 2)) % 2)  # alternate the two scheduling forms over the cases
             dev.octree_force(theta)
             dev.sync()
             size, mass = dev.octree.info(dev.stream)
@@ -43,6 +44,24 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             for k in ("m", "x", "v"):  # unlike bvh, the octree does not permute the bodies
                 assert np.array_equal(getattr(out, k), getattr(ref, k))
             dev.close()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_octree_traversal_forms_bitwise_identical(nb, dtype, dim):
+    """Per-lane walks and the wave-cooperative sweep perform each body's tests and additions in the same order."""
+    for wl, n, theta in (("galaxy", 5000, 0.5), ("uniform", 777, 0.3), ("galaxy", 40000, 0.7), ("uniform", 64, 0.0), ("uniform", 3, 0.5)):
+        out = []
+        for mode in (1, 2):
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+            dev.octree.set_traversal(mode)
+            dev.octree.enable_counters(True)
+            dev.octree_force(theta)
+            dev.sync()
+            out.append((dev.download().a.copy(), dev.octree.read_counters(dev.stream).copy()))
+            dev.close()
+        assert np.array_equal(out[0][0], out[1][0]), (wl, n, theta)
+        assert np.array_equal(out[0][1], out[1][1]), (wl, n, theta)
 
 
 def test_octree_theta0_equals_all_pairs(nb):

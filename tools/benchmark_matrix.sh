@@ -20,6 +20,8 @@ run() {
   ms=$(python3 -c "print(f'{1e3*$total/max(1,$nst):.3f}')")
   echo "$row,$ms,${GPU:-unknown},${ARCH:-unknown},$DRV,$CPU,$CORES,$CC,$(hostname)"
 }
-for algo in all-pairs all-pairs-collapsed bvh; do run $algo 100000; done
+for algo in all-pairs all-pairs-collapsed octree bvh; do run $algo 100000; done
+run octree 1000000
 run bvh 1000000
+run octree 1000000 "--theta 0.3"
 run bvh 1000000 "--theta 0.3"

@@ -55,6 +55,25 @@ def bvh(name, dtype, dim, wl, n, theta, reps):
     return {"config": name, "n": n, "theta": theta, "ms_per_step": tt * 1e3, "body_steps_per_s": n / tt, **phases}
 
 
+def octree(name, dtype, dim, wl, n, theta, reps):
+    dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+    st, t = dev.state(), dev.octree
+    phases = {}
+    def run_phase(key, fn):
+        phases[key] = timed(dev, fn, reps, warm=0) * 1e3
+    dev.octree_force(theta); dev.accelerate_step(); dev.sync()
+    run_phase("bounds_ms", lambda: t.compute_bounds(st, dev.stream))
+    run_phase("insert_ms", lambda: t.insert(st, dev.stream))
+    run_phase("multipoles_ms", lambda: t.compute_tree(dev.stream))
+    run_phase("force_ms", lambda: t.compute_force(st, theta, dev.stream))
+    run_phase("accel_ms", lambda: dev.accelerate_step())
+    size, _ = t.info(dev.stream)
+    g = nb.StepGraph(dev, lambda: (dev.octree_force(theta), dev.accelerate_step()))
+    tt = timed(dev, g.launch, reps)
+    g.close(); n = dev.n; dev.close()
+    return {"config": name, "n": n, "theta": theta, "ms_per_step": tt * 1e3, "body_steps_per_s": n / tt, "tree_size": int(size), **phases}
+
+
 out = []
 out.append(all_pairs("C2 all-pairs 3D double n=65536 (uniform, the default workload)", nb.F64, 3, "uniform", 65536, 20))
 out.append(all_pairs("C3 all-pairs-collapsed 3D float n=262144 (uniform)", nb.F32, 3, "uniform", 262144, 5, collapsed=True))
@@ -66,5 +85,8 @@ out.append(all_pairs("C1-size all-pairs 2D float n=10000 (uniform)", nb.F32, 2, 
 out.append(all_pairs("ref matrix: all-pairs 3D double n=100000 galaxy", nb.F64, 3, "galaxy", 100000, 10))
 out.append(all_pairs("ref matrix: all-pairs-collapsed 3D double n=100000 galaxy", nb.F64, 3, "galaxy", 100000, 10, collapsed=True))
 out.append(bvh("ref matrix: bvh 3D double n=100000 galaxy theta=0.5", nb.F64, 3, "galaxy", 100000, 0.5, 20))
+out.append(octree("ref matrix: octree 3D double n=100000 galaxy theta=0.5", nb.F64, 3, "galaxy", 100000, 0.5, 20))
+out.append(octree("ref matrix: octree 3D double n=1e6 galaxy theta=0.5", nb.F64, 3, "galaxy", 1000000, 0.5, 5))
+out.append(octree("octree 3D float n=1e6 galaxy theta=0.5", nb.F32, 3, "galaxy", 1000000, 0.5, 5))
 out.append(bvh("bvh 3D float n=1e6 galaxy theta=0.5", nb.F32, 3, "galaxy", 1000000, 0.5, 5))
 print(json.dumps({"device": nb.device_info()[0], "results": out}, indent=1))

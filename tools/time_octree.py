@@ -1,0 +1,38 @@
+"""Diagnostic: per-phase time of the octree step (clear, bounds, insert, multipoles, force) and of the bvh step at the same N."""
+import sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+from conftest import load_package
+nb = load_package()
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
+dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64
+wl = sys.argv[3] if len(sys.argv) > 3 else "galaxy"
+dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, wl, n))
+st, t = dev.state(), dev.octree
+
+
+def timed(name, fn, reps=5):
+    fn(); dev.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    dev.sync()
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    print(f"n={n} {wl} dtype={dtype} {name}: {ms:.3f} ms", flush=True)
+    return ms
+
+
+tot = 0.0
+tot += timed("octree clear", lambda: t.clear(dev.stream))
+tot += timed("octree bounds", lambda: t.compute_bounds(st, dev.stream))
+tot += timed("octree insert", lambda: t.insert(st, dev.stream))
+tot += timed("octree multipoles", lambda: t.compute_tree(dev.stream))
+t.set_traversal(1)
+timed("octree force, per-lane walks", lambda: t.compute_force(st, 0.5, dev.stream))
+t.set_traversal(2)
+timed("octree force, wave sweep", lambda: t.compute_force(st, 0.5, dev.stream))
+t.set_traversal(0)
+tot += timed("octree force", lambda: t.compute_force(st, 0.5, dev.stream))
+print(f"octree phases sum {tot:.3f} ms; tree info {t.info(dev.stream)}")
+timed("octree whole step", lambda: nb.run(dev, "octree", 1, 0.5))
+d2 = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, wl, n))
+timed("bvh whole step", lambda: nb.run(d2, "bvh", 1, 0.5))

@@ -182,53 +182,58 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
   }
 }
 
+// One thread per (cell, child): the 2^D lanes of a cell search their lower bounds side by side (the top levels are pure
+// latency: one cell, ~20 dependent probes per search), take the upper bound from the neighbour lane and write one child
+// record each — a cell's sibling group is one contiguous 2^D-record store.  Children that must be split are appended to
+// the next level's cell list with ONE counter bump per 1024-thread block: returning same-address atomics complete at
+// ~12 ns each on this chip whatever else the kernel does (one per wave made the widest level 402 us, 37k atomics).
+constexpr int kOBuild = 1024;
 template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
-                                                             const uint32_t* __restrict__ sidx, const T* __restrict__ m,
-                                                             const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
-                                                             ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
-                                                             uint32_t* __restrict__ flags, uint32_t capacity, uint32_t max_cells) {
+__global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
+                                                                 const uint32_t* __restrict__ sidx, const T* __restrict__ m,
+                                                                 const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
+                                                                 ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
+                                                                 uint32_t* __restrict__ flags, uint32_t capacity,
+                                                                 uint32_t max_cells) {
   constexpr uint32_t NCH = 1u << D;
-  const uint32_t count   = lvl_count[level];
-  const uint32_t k       = blockIdx.x * kOB + threadIdx.x;
-  if (k >= count) return;
+  __shared__ uint32_t wave_first[kOBuild / 64];
+  __shared__ uint32_t block_first;
+  const uint32_t count = lvl_count[level];
+  if (blockIdx.x * (kOBuild / NCH) >= count) return;  // whole blocks beyond this level's cells
+  const uint32_t tid = blockIdx.x * kOBuild + threadIdx.x;
+  const uint32_t k = tid / NCH, c = tid % NCH;
   uint32_t base = 0;  // cells of the shallower levels = rank of this level's first cell
   for (int j = 0; j < level; ++j) base += lvl_count[j];
   const uint32_t rank = base + k;
-  const ot_cell cell  = cells[rank];
   const uint32_t fc   = 1u + rank * NCH;  // its sibling group (the reference's bump allocator hands out the same shape)
-  if (level >= kMaxLevels<D>) {           // >= 2 bodies share every key digit: deeper than the keys resolve
-    atomicOr(flags, kFlagDepth);  // the node stays an (empty) leaf; nbody_octree_info reports the error
-    return;
+  bool live           = k < count;        // lane groups of a cell stay together
+  if (live && level >= kMaxLevels<D>) {   // >= 2 bodies share every key digit: deeper than the keys resolve
+    if (c == 0) atomicOr(flags, kFlagDepth);  // the node stays an (empty) leaf; nbody_octree_info reports the error
+    live = false;
   }
-  if (fc + NCH > capacity) {
-    atomicOr(flags, kFlagCapacity);
-    return;
+  if (live && fc + NCH > capacity) {
+    if (c == 0) atomicOr(flags, kFlagCapacity);
+    live = false;
   }
-  const T child_side       = nodes[cell.node].side / T(2);  // src/octree.h:245
-  const uint32_t cell_skip = nodes[cell.node].skip;
-  nodes[cell.node].fc      = fc;
-
-  // child ranges: bodies are sorted by key, so the bodies of hyperant c are those whose digit at this level is c
-  const int shift = D * (kMaxLevels<D> - 1 - level);
-  uint32_t bound[NCH + 1];
-  bound[0]   = cell.start;
-  bound[NCH] = cell.end;
-#pragma unroll
-  for (uint32_t c = 1; c < NCH; ++c) {  // first position whose digit is >= c
-    uint32_t lo = bound[c - 1], hi = cell.end;
-    while (lo < hi) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if (((skeys[mid] >> shift) & (NCH - 1)) < c) lo = mid + 1;
-      else hi = mid;
+  uint32_t lo = 0, end = 0;
+  const uint32_t ci = fc + c;
+  if (live) {
+    const ot_cell cell       = cells[rank];
+    const T child_side       = nodes[cell.node].side / T(2);  // src/octree.h:245
+    const uint32_t cell_skip = nodes[cell.node].skip;
+    // child ranges: bodies are sorted by key, so the bodies of hyperant c are those whose digit at this level is c
+    const int shift = D * (kMaxLevels<D> - 1 - level);
+    uint32_t hi     = cell.end;
+    lo              = cell.start;
+    if (c != 0) {  // first position whose digit is >= c
+      while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2;
+        if (((skeys[mid] >> shift) & (NCH - 1)) < c) lo = mid + 1;
+        else hi = mid;
+      }
     }
-    bound[c] = lo;
-  }
-  const uint32_t next_base = base + count;
-#pragma unroll
-  for (uint32_t c = 0; c < NCH; ++c) {
-    const uint32_t cnt = bound[c + 1] - bound[c];
-    const uint32_t ci  = fc + c;
+    const uint32_t up = __shfl_down(lo, 1, NCH);
+    end               = c + 1 < NCH ? up : cell.end;
     ot_node<T> r;
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.p[q] = T(0);
@@ -236,19 +241,37 @@ __global__ __launch_bounds__(kOB) void ot_build_level_kernel(int level, const ui
     r.side = child_side;
     r.fc   = kOtEmpty;
     r.skip = c + 1 < NCH ? ci + 1u : cell_skip;  // next sibling, else wherever the walk goes after the parent
-    if (cnt == 1) {                              // leaf with one body (src/octree.h:140-145, :163-165)
-      const uint64_t b = sidx[bound[c]];
+    if (end - lo == 1) {                         // leaf with one body (src/octree.h:140-145, :163-165)
+      const uint64_t b = sidx[lo];
 #pragma unroll
       for (int q = 0; q < D; ++q) r.p[q] = x[b * D + q];
       r.m  = m[b];
       r.fc = kOtBody;
     }
     nodes[ci] = r;
-    if (cnt >= 2) {  // split it on the next level (which sets its fc)
-      const uint32_t pos = atomicAdd(&lvl_count[level + 1], 1u);
-      if (next_base + pos < max_cells) cells[next_base + pos] = ot_cell{ci, bound[c], bound[c + 1]};
-      else atomicOr(flags, kFlagCapacity);
+    if (c == 0) nodes[cell.node].fc = fc;
+  }
+  // children holding >= 2 bodies are split on the next level (which sets their fc)
+  const bool split      = live && end - lo >= 2;
+  const uint64_t voters = __ballot(split);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) wave_first[wave] = uint32_t(__builtin_popcountll(voters));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t total = 0;
+    for (int w = 0; w < kOBuild / 64; ++w) {
+      const uint32_t n_w = wave_first[w];
+      wave_first[w]      = total;
+      total += n_w;
     }
+    block_first = total != 0 ? atomicAdd(&lvl_count[level + 1], total) : 0u;
+  }
+  __syncthreads();
+  if (split) {
+    const uint32_t pos =
+        base + count + block_first + wave_first[wave] + uint32_t(__builtin_popcountll(voters & ((1ull << lane) - 1ull)));
+    if (pos < max_cells) cells[pos] = ot_cell{ci, lo, end};
+    else atomicOr(flags, kFlagCapacity);
   }
 }
 
@@ -540,7 +563,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
   for (int l = 0; l <= kMaxLevels<D>; ++l) {
     const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
-    hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
+    hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l * NCH + kOBuild - 1) / kOBuild)), dim3(kOBuild), 0, st, l,
                        t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), nodes, t->cells,
                        t->lvl_count, flags, t->capacity, t->max_cells);
     NB_HIP(hipGetLastError());

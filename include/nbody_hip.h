@@ -156,7 +156,9 @@ int nbody_octree_compute_tree(nbody_octree* t, void* stream);
 /* octree::compute_force (src/octree.h:226-263): a[i] = c * sum over the stackless walk with side/dx < theta. */
 int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream);
 /* Blocking.  tree_size = next_free_child_group (printed by --print-info, src/octree.h:314), root_mass = m[0].mass()
- * as one T; either may be NULL.  Fails if the build hit the depth limit or exhausted the node pool. */
+ * as one T; either may be NULL.  Fails if ANY build since the previous call hit the depth limit or exhausted the node
+ * pool (the device-side flag is sticky; this call reports and clears it) — a caller that replays recorded steps checks once
+ * at the end of the run. */
 int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, void* stream);
 /* Test/diagnostic: per-body {nodes examined, terms accumulated} u32[n][2] of the last compute_force. */
 int nbody_octree_enable_counters(nbody_octree* t, int on);

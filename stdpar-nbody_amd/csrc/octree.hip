@@ -157,11 +157,9 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
 // ---- breadth-first build --------------------------------------------------------------------------------------------
 template <typename T, int D>
 __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, const T* __restrict__ root,
-                                     ot_node<T>* __restrict__ nodes, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
-                                     uint32_t* __restrict__ flags) {
+                                     ot_node<T>* __restrict__ nodes, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
-  if (threadIdx.x == 0) {
-    flags[0] = 0;
+  if (threadIdx.x == 0) {  // (the overflow flags behind lvl_count are sticky: nbody_octree_info reports and clears them)
     ot_node<T> r;
 #pragma unroll
     for (int k = 0; k < 3; ++k) r.p[k] = T(0);
@@ -558,7 +556,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   t->sorted_buf = fin;
   uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells, t->lvl_count, flags);
+                     static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
   for (int l = 0; l <= kMaxLevels<D>; ++l) {
@@ -652,6 +650,7 @@ extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint3
   NB_ALLOC(t->cells, sizeof(ot_cell) * size_t(t->max_cells));
   NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 3));
 #undef NB_ALLOC
+  if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 3)); e != hipSuccess) return fail(e, "hipMemset");
   *out = t;
   return NBODY_OK;
 }
@@ -757,7 +756,8 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
   char rec[32];
   NB_HIP(hipMemcpyAsync(rec, t->nodes, t->tsz * 4, hipMemcpyDeviceToHost, st));
   NB_HIP(hipStreamSynchronize(st));
-  const uint32_t flags = lv[maxl + 2];
+  const uint32_t flags = lv[maxl + 2];  // set by ANY build since the last call
+  if (flags != 0) NB_HIP(hipMemsetAsync(t->lvl_count + (maxl + 2), 0, sizeof(uint32_t), st));
   if (flags & kFlagDepth) {
     set_error("octree depth limit: at least two bodies share all %d key levels (closer than root_side/2^%d in every coordinate)",
               maxl, maxl);

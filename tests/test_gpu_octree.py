@@ -131,6 +131,16 @@ def test_octree_errors(nb):
     dev.sync()
     with pytest.raises(nb.NbodyError, match="depth limit"):
         dev.octree.info(dev.stream)
+    # the flag is sticky across builds (a run that replays recorded steps checks once, at the end) and cleared by the report
+    hs2 = dev.download()
+    dev.octree_force(0.5)      # bad build
+    hs2.x[2] = [1.5, 1.0, 1.25]
+    dev.upload(hs2)
+    dev.octree_force(0.5)      # good build afterwards
+    with pytest.raises(nb.NbodyError, match="depth limit"):
+        dev.octree.info(dev.stream)
+    size, mass = dev.octree.info(dev.stream)
+    assert size == 1 + 8 * ((size - 1) // 8) and mass == 4.0
     d2 = nb.DeviceSystem.from_host(nb.build_model(1, 3, "uniform", 50))
     with pytest.raises(nb.NbodyError, match="before nbody_octree_compute_bounds"):
         d2.octree.insert(d2.state(), d2.stream)

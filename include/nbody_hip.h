@@ -163,8 +163,11 @@ int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, voi
 /* Test/diagnostic: per-body {nodes examined, terms accumulated} u32[n][2] of the last compute_force. */
 int nbody_octree_enable_counters(nbody_octree* t, int on);
 int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream);
-/* Scheduling form of compute_force, as nbody_bvh_set_traversal: 0 = auto, 1 = one walk per lane, 2 = wave-cooperative
- * sweep of the union of the 64 lanes' walks.  Results and counters are bitwise identical. */
+/* Scheduling form of compute_force: 0 = auto (currently 3), 1 = one walk per lane, 2 = wave-cooperative sweep of the
+ * union of the 64 lanes' walks, 3 = sibling-group walks (2^dim lanes per body examine the children of an opened node
+ * side by side).  All forms perform the same opening tests and accumulate the same terms per body (identical counters);
+ * 1 and 2 add them in the reference's walk order and are bitwise identical to each other, 3 adds them per child slot and
+ * combines the 2^dim partial sums (differences at rounding level). */
 int nbody_octree_set_traversal(nbody_octree* t, int mode);
 
 /* ---- owning context (device mirrors of a host System), used by the C++ CLI host ------------------ */

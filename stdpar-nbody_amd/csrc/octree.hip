@@ -49,8 +49,8 @@ template <typename T>
 struct alignas(8 * sizeof(T)) ot_node {
   T p[3];
   T m;
+  uint32_t fc, lvl, skip;  // lvl: depth of the node; side == root_side * 2^-lvl exactly (what the group walk uses: 8 B less per visit)
   T side;
-  uint32_t fc, skip;
 };
 static_assert(sizeof(ot_node<double>) == 64 && sizeof(ot_node<float>) == 32, "one aligned record per node");
 
@@ -165,6 +165,7 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
     for (int k = 0; k < 3; ++k) r.p[k] = T(0);
     r.m    = T(0);
     r.side = root[D];
+    r.lvl  = 0;
     r.fc   = kOtEmpty;
     r.skip = kOtEmpty;  // the walk ends after the root's subtree
     if (n >= 2) {       // the root holds >= 2 bodies: it is the first cell to split
@@ -237,6 +238,7 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
     for (int q = 0; q < 3; ++q) r.p[q] = T(0);
     r.m    = T(0);  // empty leaf: zero monopole (src/octree.h:77-83); a cell's monopole is filled in by the multipole pass
     r.side = child_side;
+    r.lvl  = uint32_t(level) + 1u;
     r.fc   = kOtEmpty;
     r.skip = c + 1 < NCH ? ci + 1u : cell_skip;  // next sibling, else wherever the walk goes after the parent
     if (end - lo == 1) {                         // leaf with one body (src/octree.h:140-145, :163-165)
@@ -312,6 +314,11 @@ template <typename T>
 __device__ __forceinline__ T ot_sqrt(T v) {
   if constexpr (sizeof(T) == 4) return __builtin_sqrtf(v);  // correctly rounded (HIP default for f32 sqrt/div)
   else return __builtin_sqrt(v);
+}
+template <typename T>
+__device__ __forceinline__ T ot_ldexp(T v, int e) {
+  if constexpr (sizeof(T) == 4) return __builtin_ldexpf(v, e);
+  else return __builtin_ldexp(v, e);
 }
 template <typename T>
 __device__ __forceinline__ T ot_rsq(T v) {  // hardware seed: 1 ulp (f32) / ~2^-24 (f64, profiles/r01_valu_rates_microbench.txt)
@@ -480,6 +487,107 @@ __device__ __forceinline__ void ot_walk_wave(uint32_t t, const ot_node<T>* __res
   }
 }
 
+// Sibling-group walks: 2^D lanes per body.  When a node is opened its 2^D children are examined side by side, one per lane
+// (one coalesced 2^D-record load), the ones to open are pushed on the body's stack in LDS in reverse child order and the
+// walk continues with the popped one: the dependent chain of a body is the number of nodes it OPENS (~180 at N = 10^6,
+// theta 0.5) instead of the number it visits (~1430), which is what the per-lane form's time is made of while the chip
+// is not full.  Each lane sums the terms of its own child slots and the 2^D partial sums are combined at the end, so the
+// summation ORDER differs from the reference's walk (tolerance parity; tests, accepted terms and counters are the same
+// set, and the result of a body still depends on nothing but the tree and that body).
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_group_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                                            const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
+                                                            uint32_t first, uint32_t count, T theta, uint32_t capacity,
+                                                            const T* __restrict__ root, uint32_t* __restrict__ counters) {
+  constexpr uint32_t NCH   = 1u << D;
+  constexpr uint32_t GPW   = 64u / NCH;                                // bodies per wave
+  constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;          // a pop frees one slot, an open adds <= 2^D
+  __shared__ uint32_t stack[GPW][DEPTH];
+  const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
+  const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
+  const uint32_t body = t < sz ? sidx[t] : kOtEmpty;
+  const bool valid    = t < sz && body >= first && body - first < count;
+  const ot_theta<T> th(theta);
+  T xi[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
+    acc[k] = T(0);
+  }
+  uint32_t c_nodes = 0, c_terms = 0;
+  uint32_t cur = 0, sp = 0;
+  bool more = false;
+  const T root_side = root[D];
+  if (valid) {  // the root is examined alone (by every lane of the group; lane 0 keeps the result)
+    const ot_node<T> nd = nodes[0];
+    T di[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    const T d2      = ot_dist2<T, D>(di);
+    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
+    const T y0      = ot_rsq(d2a);
+    const bool leaf = nd.fc >= kOtBody;
+    const bool take = leaf || ot_accept<T>(!leaf, nd.side, d2, y0, th);
+    if (take) ot_accumulate<T, D>(cc == 0, acc, di, nd.m, d2a, y0);
+    if (COUNT && cc == 0) {
+      c_nodes = 1;
+      c_terms = take;
+    }
+    more = !take;
+    cur  = nd.fc;
+  }
+  uint32_t guard = capacity;
+  while (more && guard-- != 0u) {  // the lanes of a group leave together
+    // 40 of the record's 64 bytes (24 of 32 in f32): monopole, then (fc, lvl) as one load
+    const ot_node<T>* rec = nodes + (cur + cc);
+    struct { T p[3]; T m; uint32_t fc, lvl; } nd;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) nd.p[k] = rec->p[k];
+    nd.m = rec->m;
+    {
+      const uint64_t fl = *reinterpret_cast<const uint64_t*>(&rec->fc);
+      nd.fc  = uint32_t(fl);
+      nd.lvl = uint32_t(fl >> 32);
+    }
+    T di[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    const T d2      = ot_dist2<T, D>(di);
+    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
+    const T y0      = ot_rsq(d2a);
+    const bool leaf = nd.fc >= kOtBody;
+    const bool take = leaf || ot_accept<T>(!leaf, ot_ldexp(root_side, -int(nd.lvl)), d2, y0, th);
+    if (COUNT) {
+      ++c_nodes;
+      c_terms += take;
+    }
+    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2a, y0);
+    const uint32_t open_mask = uint32_t((__ballot(!take) >> (g * NCH)) & ((1ull << NCH) - 1ull));
+    if (!take) stack[g][sp + uint32_t(__builtin_popcount(open_mask >> (cc + 1u)))] = nd.fc;  // reverse child order
+    sp += uint32_t(__builtin_popcount(open_mask));
+    if (sp == 0u) break;
+    cur = stack[g][--sp];
+  }
+  // combine the 2^D partial sums of a body (fixed order)
+#pragma unroll
+  for (uint32_t off = NCH / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] += __shfl_xor(acc[k], int(off), 64);
+    if (COUNT) {
+      c_nodes += __shfl_xor(c_nodes, int(off), 64);
+      c_terms += __shfl_xor(c_terms, int(off), 64);
+    }
+  }
+  if (valid && cc == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(body) * 2 + 0] = c_nodes;
+      counters[uint64_t(body) * 2 + 1] = c_terms;
+    }
+  }
+}
+
 // Mixing the forms on a CU (k of every 8 blocks sweeping, so that the walks load the texture-address unit and the sweeps the
 // VALU) was measured and does not help: 5.05-5.3 ms for every k at N = 10^6 — a sweeping wave's 3.6k dependent steps are
 // then the critical path.
@@ -516,7 +624,7 @@ struct nbody_octree {
   uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
   uint32_t* counters = nullptr;
   int sorted_buf   = 0;
-  int traversal    = 0;  // 0 auto, 1 per-lane walks, 2 wave-cooperative sweep
+  int traversal    = 0;  // 0 auto (= 3), 1 per-lane walks, 2 wave-cooperative sweep, 3 sibling-group walks
   bool counters_on = false, have_bounds = false, inserted = false, have_tree = false;
 };
 
@@ -590,9 +698,23 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
   if (s->count == 0) return NBODY_OK;
   const uint32_t blocks = (s->sz + 63) / 64;
   auto* nodes           = static_cast<const ot_node<T>*>(t->nodes);
-  // auto: the per-lane walks are the faster form in f64 at every size measured (5.1 vs 5.4 ms at N = 10^6; 0.54 vs 1.2 ms
-  // at 10^5); in f32 the sweep wins from ~600k bodies (3.35 vs 3.61 ms at 10^6)   [tools/time_octree.py, one MI355X]
-  const bool wave = t->traversal == 2 || (t->traversal == 0 && sizeof(T) == 4 && s->count >= 600000u);
+  // auto = sibling-group walks: fastest at every size measured on one MI355X (tools/time_octree.py, galaxy theta 0.5, f64:
+  // 3.8 / 5.0 / 5.4 ms group / per-lane / sweep at N = 10^6, 0.34 / 0.54 / 1.2 ms at 10^5, 0.05 / 0.26 / 0.61 ms at 10^4;
+  // f32 at 10^6: 1.7 / 3.2 / 3.3 ms).  Forms 1 and 2 add each body's terms in the reference's order.
+  const bool wave = t->traversal == 2;
+  if (t->traversal == 3 || t->traversal == 0) {
+    const uint32_t gblocks = (s->sz + (64u >> D) - 1) / (64u >> D);
+    if (t->counters_on)
+      hipLaunchKernelGGL((ot_force_group_kernel<T, D, true>), dim3(gblocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],
+                         static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                         static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters);
+    else
+      hipLaunchKernelGGL((ot_force_group_kernel<T, D, false>), dim3(gblocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],
+                         static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                         static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters);
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
 #define NB_OT_LAUNCH(KERN, CNT)                                                                                                  \
   hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf], static_cast<const T*>(s->x), \
                      static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, static_cast<T>(theta), t->capacity, \
@@ -731,7 +853,7 @@ extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s,
 
 extern "C" int nbody_octree_set_traversal(nbody_octree* t, int mode) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
-  NB_ARG(mode >= 0 && mode <= 2, "traversal mode must be 0 (auto), 1 (per-lane) or 2 (wave-cooperative), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 3, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative) or 3 (sibling groups), got %d", mode);
   t->traversal = mode;
   return NBODY_OK;
 }

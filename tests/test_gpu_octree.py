@@ -31,7 +31,7 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             ref = oracle.build_model(dtype, dim, wl, n)
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.octree.enable_counters(True)
-            dev.octree.set_traversal(1 + (n + int(theta * 2)) % 2)  # alternate the two scheduling forms over the cases
+            dev.octree.set_traversal(1 + (n + int(theta * 2)) % 3)  # alternate the three scheduling forms over the cases
             dev.octree_force(theta)
             dev.sync()
             size, mass = dev.octree.info(dev.stream)
@@ -52,7 +52,7 @@ def test_octree_traversal_forms_bitwise_identical(nb, dtype, dim):
     """Per-lane walks and the wave-cooperative sweep perform each body's tests and additions in the same order."""
     for wl, n, theta in (("galaxy", 5000, 0.5), ("uniform", 777, 0.3), ("galaxy", 40000, 0.7), ("uniform", 64, 0.0), ("uniform", 3, 0.5)):
         out = []
-        for mode in (1, 2):
+        for mode in (1, 2, 3):
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.octree.set_traversal(mode)
             dev.octree.enable_counters(True)
@@ -62,6 +62,9 @@ def test_octree_traversal_forms_bitwise_identical(nb, dtype, dim):
             dev.close()
         assert np.array_equal(out[0][0], out[1][0]), (wl, n, theta)
         assert np.array_equal(out[0][1], out[1][1]), (wl, n, theta)
+        # sibling-group walks: same tests and terms (counters), another summation order
+        assert np.array_equal(out[0][1], out[2][1]), (wl, n, theta)
+        assert maxrel(out[2][0], out[0][0]) <= (1e-13 if dtype == 1 else 1e-5), (wl, n, theta)
 
 
 def test_octree_theta0_equals_all_pairs(nb):

@@ -153,7 +153,9 @@ int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s, void* str
 int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* stream);
 /* octree::compute_tree (src/octree.h:183-224): masses and centres of mass, children summed in child order. */
 int nbody_octree_compute_tree(nbody_octree* t, void* stream);
-/* octree::compute_force (src/octree.h:226-263): a[i] = c * sum over the stackless walk with side/dx < theta. */
+/* octree::compute_force (src/octree.h:226-263): a[i] = c * sum over the walk with side/dx < theta.  Every body performs
+ * the reference's opening tests and accumulates the reference's terms (the per-body counters are identical); the terms
+ * are added per child slot and the 2^dim partial sums combined, so sums differ from the reference's at rounding level. */
 int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream);
 /* Blocking.  tree_size = next_free_child_group (printed by --print-info, src/octree.h:314), root_mass = m[0].mass()
  * as one T; either may be NULL.  Fails if ANY build since the previous call hit the depth limit or exhausted the node
@@ -163,12 +165,6 @@ int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, voi
 /* Test/diagnostic: per-body {nodes examined, terms accumulated} u32[n][2] of the last compute_force. */
 int nbody_octree_enable_counters(nbody_octree* t, int on);
 int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream);
-/* Scheduling form of compute_force: 0 = auto (currently 3), 1 = one walk per lane, 2 = wave-cooperative sweep of the
- * union of the 64 lanes' walks, 3 = sibling-group walks (2^dim lanes per body examine the children of an opened node
- * side by side).  All forms perform the same opening tests and accumulate the same terms per body (identical counters);
- * 1 and 2 add them in the reference's walk order and are bitwise identical to each other, 3 adds them per child slot and
- * combines the 2^dim partial sums (differences at rounding level). */
-int nbody_octree_set_traversal(nbody_octree* t, int mode);
 
 /* ---- owning context (device mirrors of a host System), used by the C++ CLI host ------------------ */
 

@@ -47,7 +47,7 @@ ABI_SYMBOLS = [
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
     "nbody_octree_create", "nbody_octree_destroy", "nbody_octree_clear", "nbody_octree_compute_bounds", "nbody_octree_insert",
     "nbody_octree_compute_tree", "nbody_octree_compute_force", "nbody_octree_info", "nbody_octree_enable_counters",
-    "nbody_octree_read_counters", "nbody_octree_set_traversal", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
+    "nbody_octree_read_counters", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
     "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
 ]
@@ -237,9 +237,6 @@ class Octree:
 
     def enable_counters(self, on=True):
         _check(lib().nbody_octree_enable_counters(self.h, 1 if on else 0))
-
-    def set_traversal(self, mode):
-        _check(lib().nbody_octree_set_traversal(self.h, int(mode)))
 
     def read_counters(self, stream=None):
         out = np.zeros((self.n, 2), np.uint32)

@@ -15,9 +15,10 @@
 //             the next level.  Children are allocated after their parents, as the traversal requires
 //             (src/octree.h:248-249)
 //   multipoles  one launch per level, deepest first (src/octree.h:183-224, without the latch)
-//   force     the reference's stackless walk per body (src/octree.h:226-263); the opening test
-//             side/(sqrt(d2)+eps) < theta is evaluated with IEEE sqrt and divide so that decisions (and the per-body
-//             visit counters) are bit-exact; the accepted term m*(xj-x)/dx^3 uses one polished v_rcp_f64.
+//   force     the reference's walk per body (src/octree.h:226-263) with 2^D lanes per body: the children of an opened node
+//             are examined side by side; every opening decision side/(sqrt(d2)+eps) < theta equals the reference's
+//             bit for bit (quick bracketing test, IEEE sqrt and divide only inside the guard band), so the per-body
+//             visit counters are exact; the accepted term m*(xj-x)/dx^3 uses polished v_rsq/v_rcp seeds.
 // Depth limit: MAXL = 21 (3D) / 32 (2D) levels, i.e. bodies closer than root_side/2^MAXL in every coordinate are
 // reported as an error (the reference keeps splitting until its node pool overflows).
 #include "common.hpp"
@@ -40,17 +41,14 @@ struct ot_cell {  // an internal cell waiting to be split: its node index and it
   uint32_t node, start, end;
 };
 
-// One tree node = one aligned record of 8 scalars (64 B f64 / 32 B f32): monopole (src/octree.h:55-56 `m`), the side of
-// its cell (the reference halves/doubles a running value while it walks, src/octree.h:245,257 — power-of-two scaling is
-// exact, so the stored value has the same bits), first child (src/octree.h:52) and the node the reference's walk reaches
-// after this node's whole subtree ("rope": next sibling, or the rope of the parent for a last sibling — the closed form
-// of next_node() + the backward steps, src/octree.h:63-71,250-259).
+// One tree node = one aligned record (64 B f64 / 32 B f32): monopole (src/octree.h:55-56 `m`), first child
+// (src/octree.h:52) and depth.  The side of a node's cell is root_side * 2^-lvl EXACTLY — the reference halves a running
+// value while it descends (src/octree.h:245), and power-of-two scaling is exact — so it is not stored: a visit reads 40 B.
 template <typename T>
 struct alignas(8 * sizeof(T)) ot_node {
   T p[3];
   T m;
-  uint32_t fc, lvl, skip;  // lvl: depth of the node; side == root_side * 2^-lvl exactly (what the group walk uses: 8 B less per visit)
-  T side;
+  uint32_t fc, lvl;
 };
 static_assert(sizeof(ot_node<double>) == 64 && sizeof(ot_node<float>) == 32, "one aligned record per node");
 
@@ -158,16 +156,15 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
 template <typename T, int D>
 __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, const T* __restrict__ root,
                                      ot_node<T>* __restrict__ nodes, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
+  (void)root;
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
   if (threadIdx.x == 0) {  // (the overflow flags behind lvl_count are sticky: nbody_octree_info reports and clears them)
     ot_node<T> r;
 #pragma unroll
     for (int k = 0; k < 3; ++k) r.p[k] = T(0);
     r.m    = T(0);
-    r.side = root[D];
     r.lvl  = 0;
     r.fc   = kOtEmpty;
-    r.skip = kOtEmpty;  // the walk ends after the root's subtree
     if (n >= 2) {       // the root holds >= 2 bodies: it is the first cell to split
       cells[0]     = ot_cell{0u, 0u, n};
       lvl_count[0] = 1;
@@ -217,9 +214,7 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
   uint32_t lo = 0, end = 0;
   const uint32_t ci = fc + c;
   if (live) {
-    const ot_cell cell       = cells[rank];
-    const T child_side       = nodes[cell.node].side / T(2);  // src/octree.h:245
-    const uint32_t cell_skip = nodes[cell.node].skip;
+    const ot_cell cell = cells[rank];
     // child ranges: bodies are sorted by key, so the bodies of hyperant c are those whose digit at this level is c
     const int shift = D * (kMaxLevels<D> - 1 - level);
     uint32_t hi     = cell.end;
@@ -237,10 +232,8 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
 #pragma unroll
     for (int q = 0; q < 3; ++q) r.p[q] = T(0);
     r.m    = T(0);  // empty leaf: zero monopole (src/octree.h:77-83); a cell's monopole is filled in by the multipole pass
-    r.side = child_side;
     r.lvl  = uint32_t(level) + 1u;
     r.fc   = kOtEmpty;
-    r.skip = c + 1 < NCH ? ci + 1u : cell_skip;  // next sibling, else wherever the walk goes after the parent
     if (end - lo == 1) {                         // leaf with one body (src/octree.h:140-145, :163-165)
       const uint64_t b = sidx[lo];
 #pragma unroll
@@ -347,40 +340,50 @@ struct ot_theta {  // theta and the two guard values of the quick opening test
   __device__ explicit ot_theta(T theta) : exact(theta), lo(theta * (T(1) - T(1) / T(65536))), hi(theta * (T(1) + T(1) / T(65536))) {}
 };
 
-// dist2(x, xj) summed exactly as the reference does (src/vec.h:232-241): the opening decision depends on its bits.
+// dist2(x, xj) summed exactly as the reference does (src/vec.h:232-241): only the guard-band evaluation needs its bits.
 template <typename T, int D>
-__device__ __forceinline__ T ot_dist2(const T (&di)[D]) {
+__device__ __forceinline__ T ot_dist2_exact(const T (&di)[D]) {
 #pragma clang fp contract(off)
   T d2 = T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) d2 = d2 + di[k] * di[k];
   return d2;
 }
+// The same sum as one FMA chain started at `tiny` (differs from the exact one by ~1e-16 relative; a coincident point
+// gives `tiny`, whose square root vanishes against eps): feeds the quick test and the accepted term.
+template <typename T, int D>
+__device__ __forceinline__ T ot_dist2_fused(const T (&di)[D]) {
+  T d2 = ot_consts<T>::tiny;
+#pragma unroll
+  for (int k = 0; k < D; ++k) d2 = __builtin_elementwise_fma(di[k], di[k], d2);
+  return d2;
+}
 
 // Opening test `side / (sqrt(d2) + eps) < theta` (src/octree.h:243, src/vec.h:243-246).  The reference's decision is
 // reproduced bit-for-bit: q = side * rsq(d2) brackets the exact quotient to ~2^-23, so a lane whose q is outside
 // theta*(1 -+ 2^-16) is decided by it; if any lane that `need`s a decision is inside the band (or holds a NaN/inf), the
-// wave evaluates the IEEE sqrt and divide.  y0 = rsq(max(d2, tiny)).
-template <typename T>
-__device__ __forceinline__ bool ot_accept(bool need, T side, T d2, T y0, const ot_theta<T>& th) {
-  const T q  = side * y0;                                             // >= side / (sqrt(d2) + eps), up to the seed error
+// wave evaluates the reference's expression with IEEE sqrt and divide.  y0 = rsq(ot_dist2_fused(di)).
+template <typename T, int D>
+__device__ __forceinline__ bool ot_accept(bool need, T side, const T (&di)[D], T y0, const ot_theta<T>& th) {
+  const T q  = side * y0;                                                 // >= side / (sqrt(d2) + eps), up to the seed error
   const T ql = __builtin_elementwise_fma(-q, ot_consts<T>::eps * y0, q);  // <= it: 1/(1 + eps/s) >= 1 - eps/s
   const bool sure_take = q < th.lo, sure_open = ql > th.hi;
   bool take = sure_take;
   if (__ballot(need && !sure_take && !sure_open) != 0ull) {
 #pragma clang fp contract(off)
-    take = side / (ot_sqrt(d2) + ot_consts<T>::eps) < th.exact;
+    take = side / (ot_sqrt(ot_dist2_exact<T, D>(di)) + ot_consts<T>::eps) < th.exact;
   }
   return take;
 }
 
 // a += mj * (xj - x) / dx^3, dx = sqrt(d2) + eps (src/octree.h:240-241), for the lanes in `on`; tolerance parity: sqrt from
-// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  di = x - xj.  The body's own leaf and
-// empty leaves add exactly 0 (di == 0 or mj == 0) because dx^3 >= eps^3 keeps the weight finite.
+// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  di = x - xj, d2f = ot_dist2_fused(di),
+// y0 = rsq(d2f).  The body's own leaf and empty leaves add exactly 0 (di == 0 or mj == 0): dx^3 >= eps^3 keeps the
+// weight finite.
 template <typename T, int D>
-__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di)[D], T mj, T d2a, T y0) {
+__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di)[D], T mj, T d2f, T y0) {
 #pragma clang fp contract(off)
-  const T t  = d2a * y0;
+  const T t  = d2f * y0;
   const T e  = __builtin_elementwise_fma(-t, y0, T(1));
   const T sq = __builtin_elementwise_fma(T(0.5) * t, e, t);
   const T dx = sq + ot_consts<T>::eps;
@@ -390,124 +393,29 @@ __device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, di[k], acc[k]);
 }
 
-// Per-lane walks: lane = body (in key order), the reference's loop with the ropes in place of its backward steps.
-// Lanes drift apart in the tree, so every step is a divergent 64-line gather; the faster form while few waves are in flight.
+// One body per 2^D lanes.  When a node is opened its 2^D children are examined side by side, one per lane (their records
+// are contiguous), the ones to open are pushed on the body's stack in LDS in reverse child order and the walk continues
+// with the popped one — the order of the reference's walk.  The dependent chain of a body is the number of nodes it OPENS
+// (~180 at N = 10^6, theta 0.5), not the number it visits (~1430).  Each lane sums the terms of its own child slots and
+// the 2^D partial sums are combined at the end in a fixed order: the summation order differs from the reference's
+// (tolerance parity), the set of tests, accepted terms and therefore the counters do not, and the result of a body
+// depends on nothing but the tree and that body (so it is independent of the shard window).
 template <typename T, int D, bool COUNT>
-__device__ __forceinline__ void ot_walk_lanes(uint32_t t, const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                              const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                              uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
-  if (t >= sz) return;
-  const uint32_t body = sidx[t];
-  if (body < first || body - first >= count) return;
-  const ot_theta<T> th(theta);
-  T xi[D], acc[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xi[k]  = x[uint64_t(body) * D + k];
-    acc[k] = T(0);
-  }
-  uint32_t idx = 0, c_nodes = 0, c_terms = 0;
-  uint32_t guard = capacity;  // a well-formed tree is left after <= capacity steps; never spin on a damaged one
-  while (idx != kOtEmpty && guard-- != 0u) {
-    const ot_node<T> nd = nodes[idx];
-    T di[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
-    const T d2      = ot_dist2<T, D>(di);
-    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
-    const T y0      = ot_rsq(d2a);
-    const bool leaf = nd.fc >= kOtBody;  // kOtBody or kOtEmpty
-    const bool take = leaf || ot_accept<T>(!leaf, nd.side, d2, y0, th);
-    if (COUNT) {
-      ++c_nodes;
-      c_terms += take;
-    }
-    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2a, y0);
-    idx = take ? nd.skip : nd.fc;
-  }
-#pragma unroll
-  for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
-  if (COUNT) {
-    counters[uint64_t(body) * 2 + 0] = c_nodes;
-    counters[uint64_t(body) * 2 + 1] = c_terms;
-  }
-}
-
-// Wave-cooperative sweep: the 64 bodies of a wave (neighbours in key order) walk nearly the same nodes, so the wave walks the
-// UNION of their walks once, in the same depth-first order: the node is wave-uniform (one scalar load of its record), a
-// lane's state is the node it waits for — exactly the `idx` of its own walk — and it takes part when the sweep arrives
-// there.  The sweep descends if any participating lane opens the node, otherwise follows the rope; a lane that accepted a
-// node the sweep descends into simply waits at the rope's target, which the sweep reaches when it leaves that subtree.
-// Every lane performs its own walk's tests and additions in its own order: results are bitwise those of ot_force_kernel.
-template <typename T, int D, bool COUNT>
-__device__ __forceinline__ void ot_walk_wave(uint32_t t, const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                             const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                             uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
-  const uint32_t body = t < sz ? sidx[t] : kOtEmpty;
-  const bool valid    = t < sz && body >= first && body - first < count;
-  if (__ballot(valid) == 0ull) return;
-  const ot_theta<T> th(theta);
-  T xi[D], acc[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
-    acc[k] = T(0);
-  }
-  uint32_t wait = valid ? 0u : kOtEmpty;  // lanes outside the shard never take part
-  uint32_t idx  = 0;                      // wave-uniform
-  uint32_t c_nodes = 0, c_terms = 0;
-  uint32_t guard = capacity;
-  while (idx != kOtEmpty && guard-- != 0u) {
-    const ot_node<T> nd = nodes[idx];  // wave-uniform address: scalar loads
-    const bool active   = wait == idx;
-    T di[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
-    const T d2      = ot_dist2<T, D>(di);
-    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
-    const T y0      = ot_rsq(d2a);
-    const bool leaf = nd.fc >= kOtBody;  // wave-uniform
-    const bool take = leaf || ot_accept<T>(active, nd.side, d2, y0, th);
-    const bool acc_l = active && take, open_l = active && !take;
-    if (COUNT) {
-      c_nodes += active;
-      c_terms += acc_l;
-    }
-    if (__ballot(acc_l) != 0ull) ot_accumulate<T, D>(acc_l, acc, di, nd.m, d2a, y0);
-    wait = active ? (take ? nd.skip : nd.fc) : wait;
-    idx  = __builtin_amdgcn_readfirstlane(__ballot(open_l) != 0ull ? nd.fc : nd.skip);
-  }
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
-    if (COUNT) {
-      counters[uint64_t(body) * 2 + 0] = c_nodes;
-      counters[uint64_t(body) * 2 + 1] = c_terms;
-    }
-  }
-}
-
-// Sibling-group walks: 2^D lanes per body.  When a node is opened its 2^D children are examined side by side, one per lane
-// (one coalesced 2^D-record load), the ones to open are pushed on the body's stack in LDS in reverse child order and the
-// walk continues with the popped one: the dependent chain of a body is the number of nodes it OPENS (~180 at N = 10^6,
-// theta 0.5) instead of the number it visits (~1430), which is what the per-lane form's time is made of while the chip
-// is not full.  Each lane sums the terms of its own child slots and the 2^D partial sums are combined at the end, so the
-// summation ORDER differs from the reference's walk (tolerance parity; tests, accepted terms and counters are the same
-// set, and the result of a body still depends on nothing but the tree and that body).
-template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_group_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                                            const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
-                                                            uint32_t first, uint32_t count, T theta, uint32_t capacity,
-                                                            const T* __restrict__ root, uint32_t* __restrict__ counters) {
+__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
+                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
+                                                      uint32_t count, T theta, uint32_t capacity, const T* __restrict__ root,
+                                                      uint32_t* __restrict__ counters) {
   constexpr uint32_t NCH   = 1u << D;
-  constexpr uint32_t GPW   = 64u / NCH;                                // bodies per wave
-  constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;          // a pop frees one slot, an open adds <= 2^D
+  constexpr uint32_t GPW   = 64u / NCH;                         // bodies per wave
+  constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;  // a pop frees one slot, an open adds <= 2^D
   __shared__ uint32_t stack[GPW][DEPTH];
   const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
+  // bodies in key order (neighbours share most of their walk: cache), XCD-contiguous blocks
   const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
   const uint32_t body = t < sz ? sidx[t] : kOtEmpty;
   const bool valid    = t < sz && body >= first && body - first < count;
   const ot_theta<T> th(theta);
+  const T root_side = root[D];
   T xi[D], acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -517,18 +425,16 @@ __global__ __launch_bounds__(64) void ot_force_group_kernel(const ot_node<T>* __
   uint32_t c_nodes = 0, c_terms = 0;
   uint32_t cur = 0, sp = 0;
   bool more = false;
-  const T root_side = root[D];
   if (valid) {  // the root is examined alone (by every lane of the group; lane 0 keeps the result)
     const ot_node<T> nd = nodes[0];
     T di[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
-    const T d2      = ot_dist2<T, D>(di);
-    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
-    const T y0      = ot_rsq(d2a);
-    const bool leaf = nd.fc >= kOtBody;
-    const bool take = leaf || ot_accept<T>(!leaf, nd.side, d2, y0, th);
-    if (take) ot_accumulate<T, D>(cc == 0, acc, di, nd.m, d2a, y0);
+    const T d2f     = ot_dist2_fused<T, D>(di);
+    const T y0      = ot_rsq(d2f);
+    const bool leaf = nd.fc >= kOtBody;  // kOtBody or kOtEmpty
+    const bool take = leaf || ot_accept<T, D>(!leaf, root_side, di, y0, th);
+    if (take) ot_accumulate<T, D>(cc == 0, acc, di, nd.m, d2f, y0);
     if (COUNT && cc == 0) {
       c_nodes = 1;
       c_terms = take;
@@ -536,32 +442,30 @@ __global__ __launch_bounds__(64) void ot_force_group_kernel(const ot_node<T>* __
     more = !take;
     cur  = nd.fc;
   }
-  uint32_t guard = capacity;
+  uint32_t guard = capacity;  // a well-formed tree is left after < capacity steps; never spin on a damaged one
   while (more && guard-- != 0u) {  // the lanes of a group leave together
-    // 40 of the record's 64 bytes (24 of 32 in f32): monopole, then (fc, lvl) as one load
-    const ot_node<T>* rec = nodes + (cur + cc);
-    struct { T p[3]; T m; uint32_t fc, lvl; } nd;
+    ot_node<T> nd;
+    {  // (fc, lvl) as ONE load: left to itself hipcc fetches lvl later, inside the non-leaf branch — a second dependent miss
+      const ot_node<T>* rec = nodes + (cur + cc);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) nd.p[k] = rec->p[k];
-    nd.m = rec->m;
-    {
+      for (int k = 0; k < 3; ++k) nd.p[k] = rec->p[k];
+      nd.m              = rec->m;
       const uint64_t fl = *reinterpret_cast<const uint64_t*>(&rec->fc);
-      nd.fc  = uint32_t(fl);
-      nd.lvl = uint32_t(fl >> 32);
+      nd.fc             = uint32_t(fl);
+      nd.lvl            = uint32_t(fl >> 32);
     }
     T di[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
-    const T d2      = ot_dist2<T, D>(di);
-    const T d2a     = ot_fmax(d2, ot_consts<T>::tiny);
-    const T y0      = ot_rsq(d2a);
+    const T d2f     = ot_dist2_fused<T, D>(di);
+    const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;
-    const bool take = leaf || ot_accept<T>(!leaf, ot_ldexp(root_side, -int(nd.lvl)), d2, y0, th);
+    const bool take = leaf || ot_accept<T, D>(!leaf, ot_ldexp(root_side, -int(nd.lvl)), di, y0, th);
     if (COUNT) {
       ++c_nodes;
       c_terms += take;
     }
-    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2a, y0);
+    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2f, y0);
     const uint32_t open_mask = uint32_t((__ballot(!take) >> (g * NCH)) & ((1ull << NCH) - 1ull));
     if (!take) stack[g][sp + uint32_t(__builtin_popcount(open_mask >> (cc + 1u)))] = nd.fc;  // reverse child order
     sp += uint32_t(__builtin_popcount(open_mask));
@@ -588,25 +492,6 @@ __global__ __launch_bounds__(64) void ot_force_group_kernel(const ot_node<T>* __
   }
 }
 
-// Mixing the forms on a CU (k of every 8 blocks sweeping, so that the walks load the texture-address unit and the sweeps the
-// VALU) was measured and does not help: 5.05-5.3 ms for every k at N = 10^6 — a sweeping wave's 3.6k dependent steps are
-// then the critical path.
-template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                                      uint32_t count, T theta, uint32_t capacity, uint32_t* __restrict__ counters) {
-  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  ot_walk_lanes<T, D, COUNT>(t, nodes, sidx, x, a, c, sz, first, count, theta, capacity, counters);
-}
-template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_wave_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                                           const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
-                                                           uint32_t first, uint32_t count, T theta, uint32_t capacity,
-                                                           uint32_t* __restrict__ counters) {
-  const uint32_t t = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  ot_walk_wave<T, D, COUNT>(t, nodes, sidx, x, a, c, sz, first, count, theta, capacity, counters);
-}
-
 }  // namespace nbody
 
 // ---- host side / C ABI -----------------------------------------------------------------------------------------------
@@ -624,7 +509,6 @@ struct nbody_octree {
   uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
   uint32_t* counters = nullptr;
   int sorted_buf   = 0;
-  int traversal    = 0;  // 0 auto (= 3), 1 per-lane walks, 2 wave-cooperative sweep, 3 sibling-group walks
   bool counters_on = false, have_bounds = false, inserted = false, have_tree = false;
 };
 
@@ -696,36 +580,15 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
 template <typename T, int D>
 static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hipStream_t st) {
   if (s->count == 0) return NBODY_OK;
-  const uint32_t blocks = (s->sz + 63) / 64;
-  auto* nodes           = static_cast<const ot_node<T>*>(t->nodes);
-  // auto = sibling-group walks: fastest at every size measured on one MI355X (tools/time_octree.py, galaxy theta 0.5, f64:
-  // 3.8 / 5.0 / 5.4 ms group / per-lane / sweep at N = 10^6, 0.34 / 0.54 / 1.2 ms at 10^5, 0.05 / 0.26 / 0.61 ms at 10^4;
-  // f32 at 10^6: 1.7 / 3.2 / 3.3 ms).  Forms 1 and 2 add each body's terms in the reference's order.
-  const bool wave = t->traversal == 2;
-  if (t->traversal == 3 || t->traversal == 0) {
-    const uint32_t gblocks = (s->sz + (64u >> D) - 1) / (64u >> D);
-    if (t->counters_on)
-      hipLaunchKernelGGL((ot_force_group_kernel<T, D, true>), dim3(gblocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],
-                         static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                         static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters);
-    else
-      hipLaunchKernelGGL((ot_force_group_kernel<T, D, false>), dim3(gblocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],
-                         static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                         static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters);
-    NB_HIP(hipGetLastError());
-    return NBODY_OK;
-  }
-#define NB_OT_LAUNCH(KERN, CNT)                                                                                                  \
-  hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf], static_cast<const T*>(s->x), \
-                     static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, static_cast<T>(theta), t->capacity, \
-                     t->counters)
-  if (wave) {
-    if (t->counters_on) NB_OT_LAUNCH(ot_force_wave_kernel, true);
-    else NB_OT_LAUNCH(ot_force_wave_kernel, false);
-  } else {
-    if (t->counters_on) NB_OT_LAUNCH(ot_force_kernel, true);
-    else NB_OT_LAUNCH(ot_force_kernel, false);
-  }
+  const uint32_t per_wave = 64u >> D;
+  const uint32_t blocks   = (s->sz + per_wave - 1) / per_wave;
+  auto* nodes             = static_cast<const ot_node<T>*>(t->nodes);
+#define NB_OT_LAUNCH(CNT)                                                                                                       \
+  hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],                 \
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,       \
+                     static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters)
+  if (t->counters_on) NB_OT_LAUNCH(true);
+  else NB_OT_LAUNCH(false);
 #undef NB_OT_LAUNCH
   NB_HIP(hipGetLastError());
   return NBODY_OK;
@@ -849,13 +712,6 @@ extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s,
     using TG = decltype(tg);
     return ot_force_run<typename TG::type, TG::dim>(t, s, theta, as_stream(stream));
   });
-}
-
-extern "C" int nbody_octree_set_traversal(nbody_octree* t, int mode) {
-  NB_ARG(t != nullptr, "nbody_octree is NULL");
-  NB_ARG(mode >= 0 && mode <= 3, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative) or 3 (sibling groups), got %d", mode);
-  t->traversal = mode;
-  return NBODY_OK;
 }
 
 extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {

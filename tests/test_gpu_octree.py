@@ -1,8 +1,8 @@
 """GPU parity: octree Barnes-Hut (the reference's default --algorithm, src/octree.h) built without locks
 (path keys -> radix sort -> breadth-first split) vs the oracle's serial restatement of the reference's lock-based
 insertion.  Node numbering differs by construction; everything observable must not: tree size, root monopole
-(bit-exact), per-body visit counters (bit-exact: the opening test uses IEEE sqrt/divide) and the forces
-(tolerance: the accepted term uses a polished reciprocal)."""
+(bit-exact), per-body visit counters (bit-exact: every opening decision equals the reference's) and the forces
+(tolerance: polished hardware seeds, terms summed per child slot)."""
 import numpy as np
 import pytest
 
@@ -31,7 +31,6 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             ref = oracle.build_model(dtype, dim, wl, n)
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.octree.enable_counters(True)
-            dev.octree.set_traversal(1 + (n + int(theta * 2)) % 3)  # alternate the three scheduling forms over the cases
             dev.octree_force(theta)
             dev.sync()
             size, mass = dev.octree.info(dev.stream)
@@ -46,25 +45,17 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             dev.close()
 
 
-@pytest.mark.parametrize("dtype", [1, 0])
-@pytest.mark.parametrize("dim", [3, 2])
-def test_octree_traversal_forms_bitwise_identical(nb, dtype, dim):
-    """Per-lane walks and the wave-cooperative sweep perform each body's tests and additions in the same order."""
-    for wl, n, theta in (("galaxy", 5000, 0.5), ("uniform", 777, 0.3), ("galaxy", 40000, 0.7), ("uniform", 64, 0.0), ("uniform", 3, 0.5)):
-        out = []
-        for mode in (1, 2, 3):
-            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
-            dev.octree.set_traversal(mode)
-            dev.octree.enable_counters(True)
-            dev.octree_force(theta)
-            dev.sync()
-            out.append((dev.download().a.copy(), dev.octree.read_counters(dev.stream).copy()))
-            dev.close()
-        assert np.array_equal(out[0][0], out[1][0]), (wl, n, theta)
-        assert np.array_equal(out[0][1], out[1][1]), (wl, n, theta)
-        # sibling-group walks: same tests and terms (counters), another summation order
-        assert np.array_equal(out[0][1], out[2][1]), (wl, n, theta)
-        assert maxrel(out[2][0], out[0][0]) <= (1e-13 if dtype == 1 else 1e-5), (wl, n, theta)
+def test_octree_force_is_deterministic(nb):
+    """Two runs on fresh trees give the same bits (the build's node numbering may differ between runs; the walk does not
+    depend on it), and a body's result does not depend on which other bodies share its wave."""
+    n = 30000
+    runs = []
+    for _ in range(2):
+        dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+        dev.octree_force(0.5)
+        runs.append(dev.download().a.copy())
+        dev.close()
+    assert np.array_equal(runs[0], runs[1])
 
 
 def test_octree_theta0_equals_all_pairs(nb):

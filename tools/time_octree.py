@@ -26,13 +26,6 @@ tot += timed("octree clear", lambda: t.clear(dev.stream))
 tot += timed("octree bounds", lambda: t.compute_bounds(st, dev.stream))
 tot += timed("octree insert", lambda: t.insert(st, dev.stream))
 tot += timed("octree multipoles", lambda: t.compute_tree(dev.stream))
-t.set_traversal(1)
-timed("octree force, per-lane walks", lambda: t.compute_force(st, 0.5, dev.stream))
-t.set_traversal(2)
-timed("octree force, wave sweep", lambda: t.compute_force(st, 0.5, dev.stream))
-t.set_traversal(3)
-timed("octree force, sibling-group walks", lambda: t.compute_force(st, 0.5, dev.stream))
-t.set_traversal(0)
 tot += timed("octree force", lambda: t.compute_force(st, 0.5, dev.stream))
 print(f"octree phases sum {tot:.3f} ms; tree info {t.info(dev.stream)}")
 timed("octree whole step", lambda: nb.run(dev, "octree", 1, 0.5))

@@ -155,3 +155,34 @@ def test_octree_full_size(nb, oracle):
     assert (size, mass) == (osize, omass)
     assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt)
     assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[1]
+
+
+def test_sharded_octree_torch_path(nb):
+    """ShardedOctree (torch tensors' data_ptr() and torch's current stream through the C ABI; every 'rank' rebuilds the
+    whole tree and walks it for its own bodies): one rank and two emulated ranks give bitwise the single-context run."""
+    import torch
+    n, steps = 7001, 3
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    nb.run(dev, "octree", steps, 0.5)
+    ref = dev.download()
+    sim = nb.parallel.ShardedOctree(nb.build_model(1, 3, "galaxy", n), 0, 1, theta=0.5, torch_device=torch.device("cuda", 0))
+    for _ in range(steps):
+        sim.step()
+    torch.cuda.synchronize()
+    x, v, a = sim.gather_state()
+    assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
+    sims = [nb.parallel.ShardedOctree(nb.build_model(1, 3, "galaxy", n), r, 2, theta=0.5, torch_device=torch.device("cuda", 0))
+            for r in range(2)]
+    for s in sims:
+        s.exchange = False  # no process group here; the exchange is emulated below
+    for _ in range(steps):
+        for s in sims:
+            s.step()
+        torch.cuda.synchronize()
+        for s in sims:      # what all_gather_into_tensor does
+            for o in sims:
+                s.x[o.first:o.first + o.count] = o.x[o.first:o.first + o.count]
+    torch.cuda.synchronize()
+    assert np.array_equal(sims[0].x.cpu().numpy(), ref.x) and np.array_equal(sims[1].x.cpu().numpy(), ref.x)
+    assert np.array_equal(np.concatenate([s.v.cpu().numpy() for s in sims]), ref.v)
+    assert np.array_equal(np.concatenate([s.a.cpu().numpy() for s in sims]), ref.a)

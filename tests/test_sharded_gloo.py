@@ -32,6 +32,15 @@ class OracleOps:
         self.O.all_pairs_force(s, sim.first, sim.count)
         sim.a.numpy()[:] = s.a[sim.first:sim.first + sim.count]
 
+    def octree_create(self, dtype, dim, n):
+        return None
+
+    def octree_force(self, tree, whole, sim, theta, stream):
+        s = self._state(sim)
+        s.a = np.zeros_like(s.x)
+        self.O.octree_step_force(s, theta)
+        sim.a.numpy()[:] = s.a[sim.first:sim.first + sim.count]
+
     def accelerate_step(self, sim, stream):
         O = self.O
         sub = O.State(sim.dtype, sim.dim, sim.count)
@@ -47,7 +56,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n, steps, q):
+def _worker(rank, world, port, n, steps, q, algorithm="all-pairs"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -61,7 +70,10 @@ def _worker(rank, world, port, n, steps, q):
     for k in ("m", "x", "v", "a", "ao"):
         getattr(hs, k)[:] = getattr(o, k)
     hs.dt, hs.c = o.dt, o.c
-    sim = nb.parallel.ShardedAllPairs(hs, rank, world, ops=OracleOps())
+    if algorithm == "octree":
+        sim = nb.parallel.ShardedOctree(hs, rank, world, theta=0.5, ops=OracleOps())
+    else:
+        sim = nb.parallel.ShardedAllPairs(hs, rank, world, ops=OracleOps())
     for _ in range(steps):
         sim.step()
     x, v, a = sim.gather_state()
@@ -86,6 +98,23 @@ def test_two_rank_sharded_equals_single(n, oracle):
         assert p.exitcode == 0
     ref = oracle.build_model(oracle.F64, 3, "galaxy", n)
     oracle.run(ref, "all-pairs", steps)
+    assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
+
+
+def test_two_rank_sharded_octree_equals_single(oracle):
+    n, steps = 301, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, steps, q, "octree")) for r in range(2)]
+    for p in procs:
+        p.start()
+    x, v, a = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = oracle.build_model(oracle.F64, 3, "galaxy", n)
+    oracle.run(ref, "octree", steps, 0.5)
     assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
 
 

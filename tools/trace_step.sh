@@ -12,7 +12,9 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 name = lambda r: r["Kernel_Name"].split("(")[0].split("::")[-1][:34]
-first = name(rows[0])
+import collections
+cnt = collections.Counter(name(r) for r in rows)
+first = next(name(r) for r in rows if cnt[name(r)] >= 3 and not name(r).startswith("__amd"))  # first kernel of a step
 idx = [i for i, r in enumerate(rows) if name(r) == first]
 a, b = idx[-2], idx[-1]
 for r in rows[a:b]:

@@ -58,6 +58,41 @@ def test_octree_force_is_deterministic(nb):
     assert np.array_equal(runs[0], runs[1])
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_octree_deep_and_clustered_trees_vs_oracle(nb, oracle, dtype, dim):
+    """Hand-made inputs that drive the build deep: close pairs (split ~19 levels down), two tight far-apart clusters,
+    negative coordinates, unequal masses.  Same checks as the generator cases: tree size, root monopole and visit
+    counters bit-exact, forces within tolerance."""
+    rng = np.random.default_rng(7 + dim + 10 * dtype)
+    t = np.float64 if dtype == 1 else np.float32
+    n = 600
+    x = rng.uniform(-1.0, 1.0, (n, dim))
+    x[100:300] = 0.37 + 1e-3 * rng.standard_normal((200, dim))     # tight cluster
+    x[300:400] = -0.81 + 2e-4 * rng.standard_normal((100, dim))    # a tighter one, far away
+    for k in range(5):                                              # pairs ~2^-18 of the root side apart
+        x[400 + 2 * k + 1] = x[400 + 2 * k] + 1.2e-5 * (k + 1)
+    m = rng.uniform(0.1, 3.0, n)
+    m[::7] *= 50.0
+    for theta in (0.0, 0.4, 1.1):
+        hs = nb.HostSystem(dtype, dim, n)
+        hs.m[:], hs.x[:] = m.astype(t), x.astype(t)
+        hs.c, hs.dt = 1.0, 0.01
+        ref = oracle.State(dtype, dim, n)
+        ref.m[:], ref.x[:] = hs.m, hs.x
+        ref.c, ref.dt = hs.c, hs.dt
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.octree.enable_counters(True)
+        dev.octree_force(theta)
+        dev.sync()
+        size, mass = dev.octree.info(dev.stream)
+        ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+        assert (size, mass) == (osize, omass), (theta, size, osize)
+        assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt), theta
+        assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[dtype], theta
+        dev.close()
+
+
 def test_octree_theta0_equals_all_pairs(nb):
     """theta = 0 never approximates: the walk reaches every body leaf (README.md:122-129)."""
     n = 3000

@@ -79,6 +79,71 @@ __global__ void k_f64(double* out, unsigned long long* cyc, double b, double c) 
        : "v"(b)
        : "vcc");
     }
+    if constexpr (OP == 12)  // 8 independent f64 compares into 8 different SGPR pairs
+      asm volatile(
+       "v_cmp_gt_f64 s[20:21], %0, %8\n v_cmp_gt_f64 s[22:23], %1, %8\n v_cmp_gt_f64 s[24:25], %2, %8\n v_cmp_gt_f64 s[26:27], %3, %8\n"
+       "v_cmp_gt_f64 s[28:29], %4, %8\n v_cmp_gt_f64 s[30:31], %5, %8\n v_cmp_gt_f64 s[32:33], %6, %8\n v_cmp_gt_f64 s[34:35], %7, %8\n"
+       : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+       : "v"(b), "v"(c)
+       : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35");
+    if constexpr (OP == 13)  // 8 independent 32-bit integer compares
+      asm volatile(
+       "v_cmp_gt_i32 s[20:21], %0, %4\n v_cmp_gt_i32 s[22:23], %1, %4\n v_cmp_gt_i32 s[24:25], %2, %4\n v_cmp_gt_i32 s[26:27], %3, %4\n"
+       "v_cmp_gt_i32 s[28:29], %0, %4\n v_cmp_gt_i32 s[30:31], %1, %4\n v_cmp_gt_i32 s[32:33], %2, %4\n v_cmp_gt_i32 s[34:35], %3, %4\n"
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3)
+       : "v"(threadIdx.x)
+       : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "s28", "s29", "s30", "s31", "s32", "s33", "s34", "s35");
+    if constexpr (OP == 14)  // 8 v_cndmask_b32 on 4 registers, fixed condition
+      asm volatile(
+       "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+       "v_cndmask_b32 %0, %0, %4, vcc\n v_cndmask_b32 %1, %1, %4, vcc\n v_cndmask_b32 %2, %2, %4, vcc\n v_cndmask_b32 %3, %3, %4, vcc\n"
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3)
+       : "v"(threadIdx.x)
+       : "vcc");
+    if constexpr (OP == 16) {  // 8 independent v_cndmask_b32 (distinct destinations), condition in vcc
+      unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+      asm volatile(
+       "v_cndmask_b32 %0, %8, %9, vcc\n v_cndmask_b32 %1, %9, %10, vcc\n v_cndmask_b32 %2, %10, %11, vcc\n v_cndmask_b32 %3, %11, %8, vcc\n"
+       "v_cndmask_b32 %4, %8, %10, vcc\n v_cndmask_b32 %5, %9, %11, vcc\n v_cndmask_b32 %6, %10, %8, vcc\n v_cndmask_b32 %7, %11, %9, vcc\n"
+       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+       : "v"(u0), "v"(u1), "v"(u2), "v"(u3)
+       : "vcc");
+      u0 ^= d0 ^ d4; u1 ^= d1 ^ d5; u2 ^= d2 ^ d6; u3 ^= d3 ^ d7;
+    }
+    if constexpr (OP == 17) {  // same with the condition in an SGPR pair (VOP3 form)
+      unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+      asm volatile(
+       "v_cndmask_b32 %0, %8, %9, s[20:21]\n v_cndmask_b32 %1, %9, %10, s[20:21]\n v_cndmask_b32 %2, %10, %11, s[20:21]\n v_cndmask_b32 %3, %11, %8, s[20:21]\n"
+       "v_cndmask_b32 %4, %8, %10, s[20:21]\n v_cndmask_b32 %5, %9, %11, s[20:21]\n v_cndmask_b32 %6, %10, %8, s[20:21]\n v_cndmask_b32 %7, %11, %9, s[20:21]\n"
+       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+       : "v"(u0), "v"(u1), "v"(u2), "v"(u3)
+       : "s20", "s21");
+      u0 ^= d0 ^ d4; u1 ^= d1 ^ d5; u2 ^= d2 ^ d6; u3 ^= d3 ^ d7;
+    }
+    if constexpr (OP == 18) {  // 8 independent v_bfi_b32 (select by a VGPR bit mask)
+      unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+      asm volatile(
+       "v_bfi_b32 %0, %8, %9, %10\n v_bfi_b32 %1, %9, %10, %11\n v_bfi_b32 %2, %10, %11, %8\n v_bfi_b32 %3, %11, %8, %9\n"
+       "v_bfi_b32 %4, %8, %10, %11\n v_bfi_b32 %5, %9, %11, %8\n v_bfi_b32 %6, %10, %8, %9\n v_bfi_b32 %7, %11, %9, %10\n"
+       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+       : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+      u0 ^= d0 ^ d4; u1 ^= d1 ^ d5; u2 ^= d2 ^ d6; u3 ^= d3 ^ d7;
+    }
+    if constexpr (OP == 19) {  // 8 independent v_xor_b32 (baseline for a 32-bit op; the xor merges above cost the same)
+      unsigned d0, d1, d2, d3, d4, d5, d6, d7;
+      asm volatile(
+       "v_xor_b32 %0, %8, %9\n v_xor_b32 %1, %9, %10\n v_xor_b32 %2, %10, %11\n v_xor_b32 %3, %11, %8\n"
+       "v_xor_b32 %4, %8, %10\n v_xor_b32 %5, %9, %11\n v_xor_b32 %6, %10, %8\n v_xor_b32 %7, %11, %9\n"
+       : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+       : "v"(u0), "v"(u1), "v"(u2), "v"(u3));
+      u0 ^= d0 ^ d4; u1 ^= d1 ^ d5; u2 ^= d2 ^ d6; u3 ^= d3 ^ d7;
+    }
+    if constexpr (OP == 15)  // v_ldexp_f64
+      asm volatile(
+       "v_ldexp_f64 %0, %0, %8\n v_ldexp_f64 %1, %1, %8\n v_ldexp_f64 %2, %2, %8\n v_ldexp_f64 %3, %3, %8\n"
+       "v_ldexp_f64 %4, %4, %8\n v_ldexp_f64 %5, %5, %8\n v_ldexp_f64 %6, %6, %8\n v_ldexp_f64 %7, %7, %8\n"
+       : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7)
+       : "v"(u0 & 1u));
     if constexpr (OP == 9)  // dependent chain latency: one fma chain
       asm volatile(
        "v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n v_fma_f64 %0, %0, %8, %9\n"
@@ -198,6 +263,14 @@ int main() {
     run("v_sqrt_f64", k_f64<6>, w, 8, 1.0, 0.0);
     run("cvt f64->f32->f64 (per cvt)", k_f64<7>, w, 8, 1.0, 0.0);
     run("cmp_f64 + 2 cndmask (per triple)", k_f64<8>, w, 4, 1.0, 0.0);
+    run("v_cmp_gt_f64 (8 indep, SGPR dst)", k_f64<12>, w, 8, 1.0, 0.0);
+    run("v_cmp_gt_i32 (8 indep, SGPR dst)", k_f64<13>, w, 8, 1.0, 0.0);
+    run("v_cndmask_b32 (fixed vcc)", k_f64<14>, w, 8, 1.0, 0.0);
+    run("v_ldexp_f64", k_f64<15>, w, 8, 1.0, 0.0);
+    run("v_cndmask_b32 vcc, 8 indep (+8 xor merges; per 16 instr)", k_f64<16>, w, 16, 1.0, 0.0);
+    run("v_cndmask_b32 sgpr, 8 indep (+8 xor; per 16 instr)", k_f64<17>, w, 16, 1.0, 0.0);
+    run("v_bfi_b32, 8 indep (+8 xor; per 16 instr)", k_f64<18>, w, 16, 1.0, 0.0);
+    run("v_xor_b32, 8 indep (+8 xor; per 16 instr)", k_f64<19>, w, 16, 1.0, 0.0);
     run("v_fma_f64 dependent chain", k_f64<9>, w, 8, 1.0000001, 1e-9);
     run("mix 3 fma_f64 : 1 rsq_f64 (per instr)", k_f64<10>, w, 8, 1.0000001, 1e-9);
     run("v_fma_f64 with SGPR operand", k_f64<11>, w, 8, 1.0000001, 1e-9);

@@ -154,9 +154,8 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
 
 // ---- breadth-first build --------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, const T* __restrict__ root,
-                                     ot_node<T>* __restrict__ nodes, ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
-  (void)root;
+__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
+                                     ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
   if (threadIdx.x == 0) {  // (the overflow flags behind lvl_count are sticky: nbody_octree_info reports and clears them)
     ot_node<T> r;
@@ -548,7 +547,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   t->sorted_buf = fin;
   uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells, t->lvl_count);
+                     static_cast<const T*>(s->x), nodes, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
   for (int l = 0; l <= kMaxLevels<D>; ++l) {

@@ -84,6 +84,50 @@ def cpu_baseline(n, hs, target_seconds=15.0):
             "interactions_per_s": count * (n - 1) / t}
 
 
+class Telemetry:
+    """Samples the GPU's shader clock and socket power with `rocm-smi` (a child process, a few times per second) while the
+    timed region runs, so that the line says at which clock its numbers were measured: the kernel sits on the VALU issue
+    ceiling, its rate is proportional to the clock the box sustains under FP64 load.  Best effort — never fails the run."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.samples, self._stop = device_index, [], threading.Event()
+        self._t = threading.Thread(target=self._loop, daemon=True)
+
+    def _loop(self):
+        import re
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower", "--json"],
+                                     capture_output=True, text=True, timeout=10).stdout
+                rec = next(iter(json.loads(out).values()))
+                sclk = next((v for k, v in rec.items() if "sclk" in k.lower()), None)
+                pwr = next((v for k, v in rec.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+                mhz = re.search(r"(\d+)\s*mhz", str(sclk), re.I)
+                if mhz:
+                    self.samples.append((float(mhz.group(1)), float(pwr) if pwr not in (None, "N/A") else None))
+            except Exception:
+                pass
+            self._stop.wait(0.25)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=15)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        clk = [c for c, _ in self.samples]
+        pw = [p for _, p in self.samples if p is not None]
+        return {"source": "rocm-smi --showclocks --showpower, sampled during the timed steps", "samples": len(clk),
+                "sclk_mhz_mean": sum(clk) / len(clk), "sclk_mhz_min": min(clk), "sclk_mhz_max": max(clk),
+                "socket_power_w_mean": sum(pw) / len(pw) if pw else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -131,6 +175,9 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    telemetry = Telemetry(local_rank) if rank == 0 else None
+    if telemetry:
+        telemetry.__enter__()
     t0 = time.perf_counter()
     force_events = []
     for _ in range(args.steps):
@@ -141,6 +188,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if telemetry:
+        telemetry.__exit__()
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -175,6 +224,7 @@ def main():
                 "effective_clock_ghz": cycles / prof_s / 1e9,
                 "hbm_gbps": traffic / prof_s / 1e9 if traffic else None, "hbm_peak_gbps": 8000.0,
             }
+        tele = telemetry.summary() if telemetry else None
         out = {
             "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
             "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -184,9 +234,13 @@ def main():
                        "parallelism": "bodies sharded over %d GPU(s), RCCL all-gather(x) per step" % world if world > 1
                        else "single GPU", "split": sim.describe()},
             "pct_fp64_peak": 100.0 * whole_job_tflops / (FP64_VECTOR_PEAK_TFLOPS * world),
+            "gpu_telemetry": tele,
             "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_kernel<double,3>", "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": k1_ms,
+                         # the same fraction against the peak at the shader clock the box sustained (socket-power capped)
+                         "frac_at_measured_clock": (achieved / (FP64_VECTOR_PEAK_TFLOPS * tele["sclk_mhz_mean"] / 2400.0)
+                                                    if tele else None),
                          "rocprof": evidence,
                          "note": "north_star forbids MFMA for this path; bound is the FP64 vector pipe "
                                  "(20 algorithmic flop per ordered pair, SURVEY 8d)"},

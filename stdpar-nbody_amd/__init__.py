@@ -10,6 +10,7 @@ The directory name contains a hyphen, so import it with the loader in `tests/con
 """
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -62,6 +63,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise NbodyError(f"{LIB_PATH} is missing: run `make -C stdpar-nbody_amd` (or __graft_entry__.build())")
+        # One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64; if this library pulled in /opt/rocm's
+        # first, a later `import torch` (sharded.py, bench.py) would bring a second runtime that finds no devices
+        # ("No HIP GPUs are available").  Loaded in this order, both resolve to the copy torch brought.
+        if "torch" not in sys.modules:
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         if L.nbody_abi_version() // 1000 != 1:
             raise NbodyError(f"{LIB_PATH} has ABI version {L.nbody_abi_version()}, this binding needs major version 1")

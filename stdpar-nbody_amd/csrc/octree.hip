@@ -392,6 +392,69 @@ __device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, di[k], acc[k]);
 }
 
+// Shard windows.  The walk takes bodies in key order, the window [first, first + count) is a range of BODY indices, so the
+// owned bodies are scattered over the key order: they are compacted (order kept) into a dense list first, otherwise every
+// wave would carry one owned body among 2^(6-D) and a 1/G shard would cost as much as the whole system.
+constexpr int kOC = 1024;
+__global__ __launch_bounds__(kOC) void ot_owned_count_kernel(const uint32_t* __restrict__ sidx, uint32_t sz, uint32_t first,
+                                                             uint32_t count, uint32_t* __restrict__ block_counts) {
+  __shared__ uint32_t wsum[kOC / 64];
+  const uint32_t t = blockIdx.x * kOC + threadIdx.x;
+  const bool own   = t < sz && sidx[t] - first < count;  // unsigned: also false for sidx[t] < first
+  const uint64_t b = __ballot(own);
+  if ((threadIdx.x & 63u) == 0) wsum[threadIdx.x >> 6] = uint32_t(__builtin_popcountll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t tot = 0;
+    for (int w = 0; w < kOC / 64; ++w) tot += wsum[w];
+    block_counts[blockIdx.x] = tot;
+  }
+}
+__global__ __launch_bounds__(kOC) void ot_owned_scan_kernel(uint32_t* __restrict__ block_counts, uint32_t nblocks) {
+  __shared__ uint32_t buf[kOC];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nblocks; base += kOC) {  // exclusive scan, one chunk of 1024 block counts at a time
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < nblocks ? block_counts[i] : 0u;
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < kOC; off <<= 1) {
+      const uint32_t add = threadIdx.x >= off ? buf[threadIdx.x - off] : 0u;
+      __syncthreads();
+      buf[threadIdx.x] += add;
+      __syncthreads();
+    }
+    if (i < nblocks) block_counts[i] = carry + buf[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == kOC - 1) carry += buf[kOC - 1];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(kOC) void ot_owned_scatter_kernel(const uint32_t* __restrict__ sidx, uint32_t sz, uint32_t first,
+                                                               uint32_t count, const uint32_t* __restrict__ block_offsets,
+                                                               uint32_t* __restrict__ owned) {
+  __shared__ uint32_t wfirst[kOC / 64];
+  const uint32_t t    = blockIdx.x * kOC + threadIdx.x;
+  const uint32_t body = t < sz ? sidx[t] : 0u;
+  const bool own      = t < sz && body - first < count;
+  const uint64_t b    = __ballot(own);
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (lane == 0) wfirst[wave] = uint32_t(__builtin_popcountll(b));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < kOC / 64; ++w) {
+      const uint32_t n_w = wfirst[w];
+      wfirst[w]          = run;
+      run += n_w;
+    }
+  }
+  __syncthreads();
+  if (own) owned[block_offsets[blockIdx.x] + wfirst[wave] + uint32_t(__builtin_popcountll(b & ((1ull << lane) - 1ull)))] = body;
+}
+
 // One body per 2^D lanes.  When a node is opened its 2^D children are examined side by side, one per lane (their records
 // are contiguous), the ones to open are pushed on the body's stack in LDS in reverse child order and the walk continues
 // with the popped one — the order of the reference's walk.  The dependent chain of a body is the number of nodes it OPENS
@@ -400,19 +463,19 @@ __device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di
 // (tolerance parity), the set of tests, accepted terms and therefore the counters do not, and the result of a body
 // depends on nothing but the tree and that body (so it is independent of the shard window).
 template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ sidx,
-                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                                      uint32_t count, T theta, uint32_t capacity, const T* __restrict__ root,
+__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ list,
+                                                      uint32_t nlist, const T* __restrict__ x, T* __restrict__ a, T c,
+                                                      uint32_t first, T theta, uint32_t capacity, const T* __restrict__ root,
                                                       uint32_t* __restrict__ counters) {
   constexpr uint32_t NCH   = 1u << D;
   constexpr uint32_t GPW   = 64u / NCH;                         // bodies per wave
   constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;  // a pop frees one slot, an open adds <= 2^D
   __shared__ uint32_t stack[GPW][DEPTH];
   const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
-  // bodies in key order (neighbours share most of their walk: cache), XCD-contiguous blocks
+  // `list`: the owned bodies in key order (neighbours share most of their walk: cache); XCD-contiguous blocks
   const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
-  const uint32_t body = t < sz ? sidx[t] : kOtEmpty;
-  const bool valid    = t < sz && body >= first && body - first < count;
+  const bool valid    = t < nlist;
+  const uint32_t body = valid ? list[t] : first;
   const ot_theta<T> th(theta);
   const T root_side = root[D];
   T xi[D], acc[D];
@@ -579,12 +642,24 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
 template <typename T, int D>
 static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hipStream_t st) {
   if (s->count == 0) return NBODY_OK;
+  const uint32_t* list = t->idx[t->sorted_buf];  // whole system: the sorted body indices themselves
+  if (s->count < s->sz) {                        // shard window: compact the owned ones (scratch: the sort's other buffers)
+    uint32_t* owned       = t->idx[1 - t->sorted_buf];
+    const uint32_t nblk   = (s->sz + kOC - 1) / kOC;
+    hipLaunchKernelGGL(ot_owned_count_kernel, dim3(nblk), dim3(kOC), 0, st, list, s->sz, s->first, s->count, t->hist);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ot_owned_scan_kernel, dim3(1), dim3(kOC), 0, st, t->hist, nblk);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(ot_owned_scatter_kernel, dim3(nblk), dim3(kOC), 0, st, list, s->sz, s->first, s->count, t->hist, owned);
+    NB_HIP(hipGetLastError());
+    list = owned;
+  }
   const uint32_t per_wave = 64u >> D;
-  const uint32_t blocks   = (s->sz + per_wave - 1) / per_wave;
+  const uint32_t blocks   = (s->count + per_wave - 1) / per_wave;
   auto* nodes             = static_cast<const ot_node<T>*>(t->nodes);
-#define NB_OT_LAUNCH(CNT)                                                                                                       \
-  hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, t->idx[t->sorted_buf],                 \
-                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,       \
+#define NB_OT_LAUNCH(CNT)                                                                                                    \
+  hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, list, s->count,                     \
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
                      static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters)
   if (t->counters_on) NB_OT_LAUNCH(true);
   else NB_OT_LAUNCH(false);

@@ -27,6 +27,7 @@ tot += timed("octree bounds", lambda: t.compute_bounds(st, dev.stream))
 tot += timed("octree insert", lambda: t.insert(st, dev.stream))
 tot += timed("octree multipoles", lambda: t.compute_tree(dev.stream))
 tot += timed("octree force", lambda: t.compute_force(st, 0.5, dev.stream))
+timed("octree force, 1/8 shard window", lambda: t.compute_force(dev.state(n // 2, n // 8), 0.5, dev.stream))
 print(f"octree phases sum {tot:.3f} ms; tree info {t.info(dev.stream)}")
 timed("octree whole step", lambda: nb.run(dev, "octree", 1, 0.5))
 d2 = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, wl, n))

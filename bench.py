@@ -93,13 +93,18 @@ class Telemetry:
         import threading
         self.dev, self.samples, self._stop = device_index, [], threading.Event()
         self._t = threading.Thread(target=self._loop, daemon=True)
+        # under rocprofv3 the tool library is preloaded into every child and initialises the GPU there before `rocm-smi`
+        # (a script) re-execs its interpreter, which this pool refuses: no sampling in profiled runs, and a clean
+        # environment for the child otherwise
+        self.enabled = "rocprof" not in os.environ.get("LD_PRELOAD", "").lower()
+        self.env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.upper().startswith(("ROCP", "ROCPROF"))}
 
     def _loop(self):
         import re
         while not self._stop.is_set():
             try:
                 out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower", "--json"],
-                                     capture_output=True, text=True, timeout=10).stdout
+                                     capture_output=True, text=True, timeout=10, env=self.env).stdout
                 rec = next(iter(json.loads(out).values()))
                 sclk = next((v for k, v in rec.items() if "sclk" in k.lower()), None)
                 pwr = next((v for k, v in rec.items() if "power" in k.lower() and "(w)" in k.lower()), None)
@@ -111,12 +116,14 @@ class Telemetry:
             self._stop.wait(0.25)
 
     def __enter__(self):
-        self._t.start()
+        if self.enabled:
+            self._t.start()
         return self
 
     def __exit__(self, *exc):
         self._stop.set()
-        self._t.join(timeout=15)
+        if self.enabled:
+            self._t.join(timeout=15)
 
     def summary(self):
         if not self.samples:
@@ -235,7 +242,7 @@ def main():
                        else "single GPU", "split": sim.describe()},
             "pct_fp64_peak": 100.0 * whole_job_tflops / (FP64_VECTOR_PEAK_TFLOPS * world),
             "gpu_telemetry": tele,
-            "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_kernel<double,3>", "achieved": achieved,
+            "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_sgpr_kernel<double,3>", "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
                          "traffic": traffic, "avg_launch_ms": k1_ms,
                          # the same fraction against the peak at the shader clock the box sustained (socket-power capped)

@@ -57,7 +57,7 @@ typedef struct nbody_state {
 } nbody_state;
 
 /* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major. */
-#define NBODY_HIP_ABI_VERSION 1000
+#define NBODY_HIP_ABI_VERSION 1001
 int nbody_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -95,6 +95,11 @@ int nbody_calc_energies(const nbody_state* s, void* kinetic_out, void* potential
  * targets_per_thread in {0 (auto), 1, 2}.  The auto choice depends on sz only — never on
  * first/count — so results are bitwise independent of how bodies are sharded over GPUs. */
 int nbody_all_pairs_configure(int split, int targets_per_thread);
+/* How K1 brings a source record to the 64 lanes of a wave (same arithmetic, same order, bitwise the same result):
+ * 1 = tiles staged in LDS, read as LDS broadcasts; 2 = records packed once per call and streamed through the scalar
+ * unit into SGPRs; 0 = auto (2).  Form 2 keeps a packed-source buffer per calling stream (32 B per body, grow-only):
+ * contexts from nbody_create reserve theirs, any other stream gets it on its first call, which must not be recorded. */
+int nbody_all_pairs_source_path(int mode);
 
 /* ---- Hilbert BVH (src/bvh.h) ---------------------------------------------------------------------- */
 

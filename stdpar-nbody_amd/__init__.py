@@ -44,7 +44,7 @@ def build(verbose=False):
 # every symbol include/nbody_hip.h declares (tests/test_abi.py checks the .so exports them all)
 ABI_SYMBOLS = [
     "nbody_abi_version", "nbody_last_error", "nbody_device_info", "nbody_all_pairs_force", "nbody_all_pairs_collapsed_force",
-    "nbody_accelerate_step", "nbody_calc_energies", "nbody_all_pairs_configure", "nbody_bvh_create", "nbody_bvh_destroy",
+    "nbody_accelerate_step", "nbody_calc_energies", "nbody_all_pairs_configure", "nbody_all_pairs_source_path", "nbody_bvh_create", "nbody_bvh_destroy",
     "nbody_bvh_bounding_box", "nbody_bvh_get_bounding_box", "nbody_bvh_hilbert_sort", "nbody_bvh_build_tree",
     "nbody_octree_create", "nbody_octree_destroy", "nbody_octree_clear", "nbody_octree_compute_bounds", "nbody_octree_insert",
     "nbody_octree_compute_tree", "nbody_octree_compute_force", "nbody_octree_info", "nbody_octree_enable_counters",
@@ -113,8 +113,12 @@ def device_info(device=0):
     return arch.value.decode(), cus.value
 
 
-def configure_all_pairs(split=0, targets_per_thread=0):
+def configure_all_pairs(split=0, targets_per_thread=0, source_path=None):
+    """K1 knobs (include/nbody_hip.h): source split, targets per lane, and — when given — how a source record reaches
+    the lanes (0 auto, 1 LDS tiles, 2 scalar stream)."""
     _check(lib().nbody_all_pairs_configure(split, targets_per_thread))
+    if source_path is not None:
+        _check(lib().nbody_all_pairs_source_path(int(source_path)))
 
 
 class HostSystem:

@@ -3,13 +3,21 @@
 // K1 (replaces src/all_pairs.h:14-27).  Bound: FP64/FP32 VALU issue (no MFMA: the inner body is
 // sub/FMA/rsq/rcp, not a contraction).  Structure:
 //   * one lane per target body (R targets per lane), targets of a block held in VGPRs;
-//   * sources stream through LDS in tiles of TJ packed (x, m) records, staged by all 256 lanes with a
-//     register prefetch of the next tile so global latency hides under the current tile's math;
-//   * the source range of every tile is split over the JS waves that share a target group, so a
-//     small shard (N/8 bodies on one GPU) still puts >= 4 waves on every SIMD — one wave alone
-//     reaches only 75% of the FP64 issue rate (profiles/r01_valu_rates_microbench.txt);
+//   * sources are packed (x, m) records visited in tiles of TJ; the source range of every tile is split over
+//     the JS waves that share a target group, so a small shard (N/8 bodies on one GPU) still puts >= 4 waves
+//     on every SIMD — one wave alone reaches only 75% of the FP64 issue rate
+//     (profiles/r01_valu_rates_microbench.txt);
 //   * wave partials are combined through LDS in a fixed order, so the result is deterministic and
 //     independent of how bodies are sharded over GPUs.
+//   Two ways of bringing a source record to the 64 lanes that all need the same one:
+//   - LDS tiles (all_pairs_force_kernel): tiles staged in LDS by all 256 lanes with a register prefetch of the
+//     next tile; the inner loop reads each record as an LDS broadcast (ds_read_b128) into VGPRs;
+//   - scalar stream (all_pairs_force_sgpr_kernel, default): the record is wave-uniform, so it belongs in SGPRs:
+//     a pre-pass packs the records once per call (32 B x N), every wave streams its slice with
+//     s_load_dwordx16 two batches deep and the VALU instructions take their source operands from SGPRs.
+//     No staging loads, no LDS traffic, no barriers in the loop, half the VGPRs (occupancy 8).  Same
+//     arithmetic in the same order: bitwise the LDS kernel's result; 3 % faster at every size measured
+//     (722 vs 746 ms at N = 2^20 on the same box) on a kernel that runs at the socket power cap.
 //
 // K2 (replaces src/all_pairs.h:29-50, intended semantics).  Lanes run along the SOURCE axis (one
 // ordered pair per lane and step), each wave owns 64 targets whose positions it broadcasts with
@@ -21,6 +29,9 @@
 // over count*D scalars, FP contraction off so it is bit-identical to the reference's x86 -O2 build.
 #include "common.hpp"
 
+#include <mutex>
+#include <vector>
+
 namespace nbody {
 
 constexpr int kBlock = 256;  // 4 waves
@@ -30,6 +41,7 @@ constexpr int kTileJ = 512;  // sources per LDS tile (fixed: the rounding order 
 struct ap_config {
   int split = 0;  // 0 = auto
   int tpt   = 0;  // targets per thread, 0 = auto
+  int path  = 0;  // source path: 0 = auto (scalar stream), 1 = LDS tiles, 2 = scalar stream
 };
 static ap_config g_ap_config;
 
@@ -137,6 +149,197 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
   }
 }
 
+typedef uint32_t sgpr16 __attribute__((ext_vector_type(16)));
+// `tie` is a VGPR value the surrounding arithmetic reads (sload16) or produces (swait): the statements carry no
+// instruction for it, it only pins them in program order relative to that arithmetic (inline asm is otherwise free to
+// drift across pure FP code during instruction selection).
+template <typename V>
+__device__ __forceinline__ sgpr16 sload16(const void* p, V& tie) {  // p wave-uniform, 4-byte aligned
+  sgpr16 r;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=s"(r), "+v"(tie) : "s"(p));
+  return r;
+}
+template <typename V>
+__device__ __forceinline__ void swait(sgpr16& v, V& tie) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(tie));
+}
+
+// Scalar-stream form: pre-pass that packs (x, m) into aligned records, zero-mass padding up to a whole tile
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restrict__ m, const T* __restrict__ x,
+                                                              src_rec<T, D>* __restrict__ out, uint32_t sz, uint32_t padded) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= padded) return;
+  src_rec<T, D> r;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) r.p[k] = (k < D && j < sz) ? x[uint64_t(j) * D + (k < D ? k : 0)] : T(0);
+  r.m    = j < sz ? m[j] : T(0);
+  out[j] = r;
+}
+
+template <typename T, int D, int R, int JS>
+__global__ __launch_bounds__(kBlock) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
+                                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
+                                                                      uint32_t first, uint32_t count) {
+  using rec_t = src_rec<T, D>;
+  constexpr int TG  = kWaves / JS;
+  constexpr int TB  = TG * 64 * R;
+  constexpr int SUB = kTileJ / JS;
+  __shared__ T partial[(JS > 1) ? (JS - 1) * TG * 64 * R * D : 1];
+  const int lane   = threadIdx.x & 63;
+  const int wave   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tgroup = wave / JS;
+  const int jpart  = wave % JS;
+  T xi[R][D], acc[R][D];
+  uint32_t ti[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t local = blockIdx.x * TB + tgroup * (64 * R) + r * 64 + lane;
+    ti[r]          = local;
+    uint64_t i     = uint64_t(first) + (local < count ? local : 0u);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      xi[r][k]  = x[i * D + k];
+      acc[r][k] = T(0);
+    }
+  }
+  const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
+  const uint32_t nsteps = ntiles * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
+  constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
+  struct batch_t {
+    rec_t r[U];
+  };
+  auto batch = [&](uint32_t k) { return packed + (uint64_t(k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
+  // Two SGPR buffers, each requested (s_load_dwordx16) one compute phase before it is consumed.  Written with inline
+  // asm: hipcc folds a loop-carried load from read-only memory back into a load at the loop top and waits for it there.
+  // SMEM returns out of order, so the only usable wait is lgkmcnt(0): wait for X, request Y, consume X.
+  sgpr16 A = sload16(batch(0), xi[0][0]), B;
+  for (uint32_t k = 0; k < nsteps; k += 2 * U) {
+    swait(A, acc[0][0]);
+    B = sload16(batch(k + U), xi[0][0]);
+    {
+      const batch_t ba = __builtin_bit_cast(batch_t, A);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], ba.r[u]);
+    }
+    swait(B, acc[0][0]);
+    A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
+    {
+      const batch_t bb = __builtin_bit_cast(batch_t, B);
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], bb.r[u]);
+    }
+  }
+  swait(A, acc[0][0]);  // nothing in flight when the wave goes on
+  if constexpr (JS > 1) {
+    if (jpart > 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) partial[((((jpart - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane] = acc[r][k];
+    }
+    __syncthreads();
+    if (jpart == 0) {
+#pragma unroll
+      for (int p = 1; p < JS; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc[r][k] += partial[((((p - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane];
+    }
+  }
+  if (jpart == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (ti[r] < count) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[uint64_t(ti[r]) * D + k] = c * acc[r][k];
+      }
+    }
+  }
+}
+
+// Packed-source scratch, one buffer per stream that has called the scalar-stream form (grow-only).  A context
+// reserves its buffer when it is created (nbody_create), so that a step recorded with nbody_graph_begin never has to
+// allocate; other callers get theirs on the first call, which therefore must not be inside a capture.
+namespace {
+struct packed_slot {
+  hipStream_t stream;
+  void* ptr;
+  size_t cap;
+};
+std::mutex g_packed_mu;
+std::vector<packed_slot> g_packed_slots;
+}  // namespace
+
+int ap_scratch_get(hipStream_t st, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lock(g_packed_mu);
+  packed_slot* slot = nullptr;
+  for (auto& sl : g_packed_slots)
+    if (sl.stream == st) slot = &sl;
+  if (slot && slot->cap >= bytes) {
+    *out = slot->ptr;
+    return NBODY_OK;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (st != nullptr) (void)hipStreamIsCapturing(st, &cs);
+  if (cs != hipStreamCaptureStatusNone) {
+    set_error("all-pairs: the packed-source buffer of this stream must exist before a step is recorded "
+              "(call nbody_all_pairs_force once outside nbody_graph_begin/end, or use a context from nbody_create)");
+    return NBODY_ERR_STATE;
+  }
+  if (!slot) {
+    g_packed_slots.push_back({st, nullptr, 0});
+    slot = &g_packed_slots.back();
+  }
+  if (slot->ptr) NB_HIP(hipFree(slot->ptr));  // hipFree waits for the device: no launch still reads the old buffer
+  slot->ptr = nullptr;
+  slot->cap = 0;
+  NB_HIP(hipMalloc(&slot->ptr, bytes));
+  slot->cap = bytes;
+  *out      = slot->ptr;
+  return NBODY_OK;
+}
+
+int ap_scratch_reserve(hipStream_t st, int dtype, uint32_t n) {
+  void* p             = nullptr;
+  const size_t padded = (size_t(n) + kTileJ - 1) / kTileJ * kTileJ;
+  return ap_scratch_get(st, (dtype == NBODY_F32 ? 16u : 32u) * padded, &p);
+}
+
+void ap_scratch_release(hipStream_t st) {
+  std::lock_guard<std::mutex> lock(g_packed_mu);
+  for (size_t i = 0; i < g_packed_slots.size(); ++i) {
+    if (g_packed_slots[i].stream == st) {
+      (void)hipFree(g_packed_slots[i].ptr);
+      g_packed_slots.erase(g_packed_slots.begin() + long(i));
+      return;
+    }
+  }
+}
+
+template <typename T, int D, int R, int JS>
+static int launch_all_pairs_sgpr(const nbody_state* s, hipStream_t st) {
+  constexpr int TB = (kWaves / JS) * 64 * R;
+  uint32_t blocks  = (s->count + TB - 1) / TB;
+  if (blocks == 0) return NBODY_OK;
+  const uint32_t padded = (s->sz + kTileJ - 1) / kTileJ * kTileJ;
+  void* scratch         = nullptr;
+  if (int r = ap_scratch_get(st, sizeof(src_rec<T, D>) * size_t(padded), &scratch)) return r;
+  auto* packed = static_cast<src_rec<T, D>*>(scratch);
+  hipLaunchKernelGGL((pack_sources_kernel<T, D>), dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), packed, s->sz, padded);
+  NB_HIP(hipGetLastError());
+  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks), dim3(kBlock), 0, st, packed,
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count);
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
 template <typename T, int D, int R, int JS>
 static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
   constexpr int TB = (kWaves / JS) * 64 * R;
@@ -159,13 +362,16 @@ template <typename T, int D>
 static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   int js = g_ap_config.split ? g_ap_config.split : auto_split(s->sz);
   int r  = g_ap_config.tpt;
+  const bool scalar = g_ap_config.path != 1;
   if (r == 0) {
-    // enough waves to give every SIMD >= 8 with R = 2?  (1024 SIMDs; waves = count/64/R*JS)
+    // R = 2 halves the record traffic per pair but needs enough waves: waves = count/64/R*JS over 1024 SIMDs
+    // (measured: LDS form wants >= 8 per SIMD, the scalar form, at half the VGPRs, >= 4)
     uint64_t waves_r2 = (uint64_t(s->count) + 127) / 128 * js;
-    r                 = waves_r2 >= 8192 ? 2 : 1;
+    r                 = waves_r2 >= (scalar ? 4096u : 8192u) ? 2 : 1;
   }
-#define NB_CASE(RR, JJ) \
-  if (r == RR && js == JJ) return launch_all_pairs<T, D, RR, JJ>(s, st)
+#define NB_CASE(RR, JJ)                                                            \
+  if (r == RR && js == JJ)                                                         \
+  return scalar ? launch_all_pairs_sgpr<T, D, RR, JJ>(s, st) : launch_all_pairs<T, D, RR, JJ>(s, st)
   NB_CASE(1, 1);
   NB_CASE(1, 2);
   NB_CASE(1, 4);
@@ -384,6 +590,12 @@ extern "C" int nbody_all_pairs_configure(int split, int targets_per_thread) {
          targets_per_thread);
   g_ap_config.split = split;
   g_ap_config.tpt   = targets_per_thread;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_all_pairs_source_path(int mode) {
+  NB_ARG(mode >= 0 && mode <= 2, "source path must be 0 (auto), 1 (LDS tiles) or 2 (scalar stream), got %d", mode);
+  g_ap_config.path = mode;
   return NBODY_OK;
 }
 

@@ -167,4 +167,8 @@ __device__ __forceinline__ void pair_accumulate_if(bool take, T (&acc)[D], const
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// all_pairs.hip: per-stream packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
+int ap_scratch_reserve(hipStream_t st, int dtype, uint32_t n);
+void ap_scratch_release(hipStream_t st);
+
 }  // namespace nbody

@@ -82,6 +82,10 @@ extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int
     nbody_destroy(c);
     return r;
   }
+  if (int r = ap_scratch_reserve(c->stream, dtype, n)) {  // so that a recorded step never allocates
+    nbody_destroy(c);
+    return r;
+  }
   *out = c;
   return NBODY_OK;
 }
@@ -93,6 +97,7 @@ extern "C" void nbody_destroy(nbody_ctx* c) {
   (void)hipFree(c->v);
   (void)hipFree(c->a);
   (void)hipFree(c->ao);
+  if (c->stream) ap_scratch_release(c->stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }

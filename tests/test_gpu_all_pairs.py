@@ -77,6 +77,29 @@ def test_shard_windows_are_bitwise_identical(nb):
 
 @pytest.mark.parametrize("dtype", [1, 0])
 @pytest.mark.parametrize("dim", [3, 2])
+def test_source_paths_are_bitwise_identical(nb, dtype, dim):
+    """K1's two ways of bringing a source record to the lanes (LDS tiles / scalar stream into SGPRs) perform the same
+    arithmetic in the same order, for every (split, targets-per-lane) configuration and for shard windows."""
+    n = 5000 + 37 * dim
+    try:
+        for split, tpt in ((0, 0), (1, 1), (2, 2), (4, 1), (4, 2), (1, 2)):
+            res = []
+            for path in (1, 2):
+                nb.configure_all_pairs(split, tpt, source_path=path)
+                dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, "galaxy", n))
+                dev.all_pairs_force()
+                full = dev.download().a.copy()
+                dev.all_pairs_force(1000, 2049)  # a shard window: rows [1000, 3049) are recomputed in place
+                assert np.array_equal(dev.download().a, full), (split, tpt, path)
+                res.append(full)
+                dev.close()
+            assert np.array_equal(res[0], res[1]), (split, tpt)
+    finally:
+        nb.configure_all_pairs(0, 0, source_path=0)
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
 def test_accelerate_step_bit_exact(nb, oracle, dtype, dim):
     rng = np.random.default_rng(5)
     for n in (1, 7, 1000, 100003):

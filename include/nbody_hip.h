@@ -97,7 +97,7 @@ int nbody_calc_energies(const nbody_state* s, void* kinetic_out, void* potential
 int nbody_all_pairs_configure(int split, int targets_per_thread);
 /* How K1 brings a source record to the 64 lanes of a wave (same arithmetic, same order, bitwise the same result):
  * 1 = tiles staged in LDS, read as LDS broadcasts; 2 = records packed once per call and streamed through the scalar
- * unit into SGPRs; 0 = auto (2).  Form 2 keeps a packed-source buffer per calling stream (32 B per body, grow-only):
+ * unit into SGPRs; 0 = auto (2 once the call has several waves per SIMD, about 65 536 targets; 1 below).  Form 2 keeps a packed-source buffer per calling stream (32 B per body, grow-only):
  * contexts from nbody_create reserve theirs, any other stream gets it on its first call, which must not be recorded. */
 int nbody_all_pairs_source_path(int mode);
 

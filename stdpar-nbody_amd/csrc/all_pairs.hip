@@ -362,12 +362,16 @@ template <typename T, int D>
 static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   int js = g_ap_config.split ? g_ap_config.split : auto_split(s->sz);
   int r  = g_ap_config.tpt;
-  const bool scalar = g_ap_config.path != 1;
+  // Source path (bitwise identical results, so the choice may depend on the shard size).  The scalar stream pays an SMEM
+  // round trip per 64-byte batch, which needs several waves per SIMD to hide: measured f64, split 4, lds / sgpr:
+  // 0.16 / 0.34 ms at N = 10^4, 0.78 / 0.98 ms at 3*10^4, 3.20 / 3.11 ms at 65 536, 8.62 / 8.32 ms at 10^5, 746 / 722 ms at 2^20.
+  const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * js, waves_r2 = (uint64_t(s->count) + 127) / 128 * js;
+  const bool scalar       = g_ap_config.path == 2 || (g_ap_config.path == 0 && waves_r1 >= 4096);
   if (r == 0) {
-    // R = 2 halves the record traffic per pair but needs enough waves: waves = count/64/R*JS over 1024 SIMDs
-    // (measured: LDS form wants >= 8 per SIMD, the scalar form, at half the VGPRs, >= 4)
-    uint64_t waves_r2 = (uint64_t(s->count) + 127) / 128 * js;
-    r                 = waves_r2 >= (scalar ? 4096u : 8192u) ? 2 : 1;
+    // R = 2 halves the record traffic per pair but needs enough waves (1024 SIMDs).  Measured: the LDS form wants >= 8 per
+    // SIMD; the scalar form, at half the VGPRs, >= 4 in f64 and never pays in f32 (23.0 vs 24.8 ms at N = 262 144)
+    if (scalar) r = (sizeof(T) == 8 && waves_r2 >= 4096) ? 2 : 1;
+    else r = waves_r2 >= 8192 ? 2 : 1;
   }
 #define NB_CASE(RR, JJ)                                                            \
   if (r == RR && js == JJ)                                                         \

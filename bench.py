@@ -145,6 +145,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON: everything else written to fd 1 by this process or its libraries (RCCL
+    # prints a version banner there when a communicator is created) goes to stderr until the line is printed
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -257,7 +263,8 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(n, hs)
             except Exception as ex:  # the baseline is a reported extra; never lose the GPU line over it
                 out["cpu_baseline"] = {"value": None, "unit": "body-steps/s", "cores": 0, "kind": "port", "sample": f"failed: {ex}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -91,9 +91,9 @@ int nbody_accelerate_step(const nbody_state* s, void* stream);
 int nbody_calc_energies(const nbody_state* s, void* kinetic_out, void* potential_out, void* stream);
 
 /* Tuning knob for K1 (does not change which pairs are summed, only the split of the source range
- * over the waves of a block and hence the rounding order).  split in {0 (auto from sz), 1, 2, 4};
- * targets_per_thread in {0 (auto), 1, 2}.  The auto choice depends on sz only — never on
- * first/count — so results are bitwise independent of how bodies are sharded over GPUs. */
+ * over the waves of a block and hence the rounding order).  split in {0 (auto from sz: 8 for sz >= 65536, else 4), 1, 2,
+ * 4, 8 (8: scalar-stream form only)}; targets_per_thread in {0 (auto), 1, 2} (no effect on the result).  The auto split
+ * depends on sz only — never on first/count — so results are bitwise independent of how bodies are sharded over GPUs. */
 int nbody_all_pairs_configure(int split, int targets_per_thread);
 /* How K1 brings a source record to the 64 lanes of a wave (same arithmetic, same order, bitwise the same result):
  * 1 = tiles staged in LDS, read as LDS broadcasts; 2 = records packed once per call and streamed through the scalar

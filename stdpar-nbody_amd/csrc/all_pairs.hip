@@ -177,12 +177,15 @@ __global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restric
   out[j] = r;
 }
 
+template <int JS>
+constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the scalar-stream form
+
 template <typename T, int D, int R, int JS>
-__global__ __launch_bounds__(kBlock) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
-                                                                      const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
-                                                                      uint32_t first, uint32_t count) {
+__global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
+                                                                                   const T* __restrict__ x, T* __restrict__ a, T c,
+                                                                                   uint32_t sz, uint32_t first, uint32_t count) {
   using rec_t = src_rec<T, D>;
-  constexpr int TG  = kWaves / JS;
+  constexpr int TG  = kSgprWaves<JS> / JS;
   constexpr int TB  = TG * 64 * R;
   constexpr int SUB = kTileJ / JS;
   __shared__ T partial[(JS > 1) ? (JS - 1) * TG * 64 * R * D : 1];
@@ -324,7 +327,7 @@ void ap_scratch_release(hipStream_t st) {
 
 template <typename T, int D, int R, int JS>
 static int launch_all_pairs_sgpr(const nbody_state* s, hipStream_t st) {
-  constexpr int TB = (kWaves / JS) * 64 * R;
+  constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
   const uint32_t padded = (s->sz + kTileJ - 1) / kTileJ * kTileJ;
@@ -334,7 +337,7 @@ static int launch_all_pairs_sgpr(const nbody_state* s, hipStream_t st) {
   hipLaunchKernelGGL((pack_sources_kernel<T, D>), dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                      static_cast<const T*>(s->m), static_cast<const T*>(s->x), packed, s->sz, padded);
   NB_HIP(hipGetLastError());
-  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks), dim3(kBlock), 0, st, packed,
+  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks), dim3(64 * kSgprWaves<JS>), 0, st, packed,
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
@@ -352,11 +355,10 @@ static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
 }
 
 // Source split: chosen from sz ONLY (never from first/count) so that every shard of a multi-GPU run
-// sums in the same order as the single-GPU run.
-static int auto_split(uint32_t sz) {
-  (void)sz;
-  return 4;
-}
+// sums in the same order as the single-GPU run.  8 slices (512-thread blocks, scalar-stream form only) once the system
+// is large enough for that form: twice the waves for the same work, which is what a 1/8 shard of N = 2^20 lacks
+// (93.1 vs 97.6 ms; whole system 720 vs 730 ms; N = 65 536: 2.92 vs 3.08 ms).  Small systems keep 4.
+static int auto_split(uint32_t sz) { return sz >= 65536u ? 8 : 4; }
 
 template <typename T, int D>
 static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
@@ -365,13 +367,21 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   // Source path (bitwise identical results, so the choice may depend on the shard size).  The scalar stream pays an SMEM
   // round trip per 64-byte batch, which needs several waves per SIMD to hide: measured f64, split 4, lds / sgpr:
   // 0.16 / 0.34 ms at N = 10^4, 0.78 / 0.98 ms at 3*10^4, 3.20 / 3.11 ms at 65 536, 8.62 / 8.32 ms at 10^5, 746 / 722 ms at 2^20.
-  const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * js, waves_r2 = (uint64_t(s->count) + 127) / 128 * js;
-  const bool scalar       = g_ap_config.path == 2 || (g_ap_config.path == 0 && waves_r1 >= 4096);
+  const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * js;
+  const bool scalar       = js == 8 || g_ap_config.path == 2 || (g_ap_config.path == 0 && waves_r1 >= 4096);
+  if (js == 8 && g_ap_config.path == 1) {
+    set_error("all-pairs: the LDS-tile form has at most 4 source slices; sz = %u uses 8 (nbody_all_pairs_configure(4, ...) to force 4)",
+              s->sz);
+    return NBODY_ERR_ARG;
+  }
   if (r == 0) {
-    // R = 2 halves the record traffic per pair but needs enough waves (1024 SIMDs).  Measured: the LDS form wants >= 8 per
-    // SIMD; the scalar form, at half the VGPRs, >= 4 in f64 and never pays in f32 (23.0 vs 24.8 ms at N = 262 144)
-    if (scalar) r = (sizeof(T) == 8 && waves_r2 >= 4096) ? 2 : 1;
-    else r = waves_r2 >= 8192 ? 2 : 1;
+    // R = 2 halves the record traffic per pair; it pays when its blocks still spread evenly over the 256 CUs.
+    // Measured (scalar form, f64): N = 65 536 (512 blocks) 2.92 vs 2.95 ms, 10^5 (782 blocks) 9.40 vs 8.10 ms, 262 144
+    // (2048) 45.8 vs 46.6 ms, 2^20 720 vs 723 ms, its 1/8 shard (1024) 93.1 vs 96.0 ms; never in f32 (24.8 vs 23.0 ms at
+    // 262 144).  LDS form: >= 8 waves per SIMD.
+    const uint64_t blocks_r2 = (uint64_t(s->count) + 127) / 128;
+    if (scalar) r = (sizeof(T) == 8 && (blocks_r2 >= 2048 || (blocks_r2 >= 512 && blocks_r2 % 256 == 0))) ? 2 : 1;
+    else r = blocks_r2 * js >= 8192 ? 2 : 1;
   }
 #define NB_CASE(RR, JJ)                                                            \
   if (r == RR && js == JJ)                                                         \
@@ -383,6 +393,10 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   NB_CASE(2, 2);
   NB_CASE(2, 4);
 #undef NB_CASE
+  if (scalar && js == 8) {
+    if (r == 1) return launch_all_pairs_sgpr<T, D, 1, 8>(s, st);
+    if (r == 2) return launch_all_pairs_sgpr<T, D, 2, 8>(s, st);
+  }
   set_error("all-pairs: unsupported config split=%d targets_per_thread=%d", js, r);
   return NBODY_ERR_ARG;
 }
@@ -589,7 +603,7 @@ static int accelerate_dispatch(const nbody_state* s, hipStream_t st) {
 using namespace nbody;
 
 extern "C" int nbody_all_pairs_configure(int split, int targets_per_thread) {
-  NB_ARG(split == 0 || split == 1 || split == 2 || split == 4, "split must be 0, 1, 2 or 4 (got %d)", split);
+  NB_ARG(split == 0 || split == 1 || split == 2 || split == 4 || split == 8, "split must be 0, 1, 2, 4 or 8 (got %d)", split);
   NB_ARG(targets_per_thread >= 0 && targets_per_thread <= 2, "targets_per_thread must be 0, 1 or 2 (got %d)",
          targets_per_thread);
   g_ap_config.split = split;

@@ -59,13 +59,13 @@ def test_pair_term_accuracy(nb, oracle):
     assert abs(np.mean((na - nr) / nr)) <= 5e-16  # no systematic bias
 
 
-def test_shard_windows_are_bitwise_identical(nb):
+@pytest.mark.parametrize("n", [6000, 70001])  # 70001: the 8-slice scalar-stream form (sz >= 65536), windows of every size class
+def test_shard_windows_are_bitwise_identical(nb, n):
     """Multi-GPU property on one GPU: any split of the targets into shard windows gives bitwise the full result."""
-    n = 6000
     dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
     dev.all_pairs_force()
     full = dev.download().a.copy()
-    for parts in (2, 4, 8, 7):
+    for parts in (2, 4, 8, 7) if n < 10000 else (2, 8, 70):
         edges = [n * r // parts for r in range(parts + 1)]
         hs0 = nb.build_model(1, 3, "galaxy", n)
         d2 = nb.DeviceSystem.from_host(hs0)
@@ -82,7 +82,7 @@ def test_source_paths_are_bitwise_identical(nb, dtype, dim):
     arithmetic in the same order, for every (split, targets-per-lane) configuration and for shard windows."""
     n = 5000 + 37 * dim
     try:
-        for split, tpt in ((0, 0), (1, 1), (2, 2), (4, 1), (4, 2), (1, 2)):
+        for split, tpt in ((0, 0), (1, 1), (2, 2), (4, 1), (4, 2), (1, 2)):  # n < 65536: auto split is 4 in both forms
             res = []
             for path in (1, 2):
                 nb.configure_all_pairs(split, tpt, source_path=path)

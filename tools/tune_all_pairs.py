@@ -13,7 +13,7 @@ hs = nb.build_model(dtype, dim, "galaxy", n)
 dev = nb.DeviceSystem.from_host(hs)
 for (label, first, count) in (("full", 0, n), ("1/8 shard", 0, n // 8)):
     for path in (1, 2):
-        for js in (1, 2, 4):
+        for js in ((1, 2, 4) if path == 1 else (1, 2, 4, 8)):
             for r in (1, 2):
                 nb.configure_all_pairs(js, r, source_path=path)
                 dev.all_pairs_force(first, count); dev.sync()

@@ -145,7 +145,7 @@ uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
  * The reference inserts bodies concurrently under per-node spin locks; only node NUMBERS depend on that order.
  * Here the same spatial tree is built without locks (path keys -> radix sort -> breadth-first split), so results,
  * tree size and visit counts equal the reference's.  Whole system only for the build phases; compute_force
- * honours the shard window.  Errors found on the device (depth limit / node pool) surface in nbody_octree_info. */
+ * honours the shard window.  Errors found on the device (coincident bodies / node pool exhausted) surface in nbody_octree_info. */
 typedef struct nbody_octree nbody_octree;
 /* octree<T,N>::alloc / dealloc (src/octree.h:42-60); capacity = max(2^dim * n, 1000) nodes (src/system.h:30). */
 int  nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n);

@@ -19,8 +19,8 @@
 //             are examined side by side; every opening decision side/(sqrt(d2)+eps) < theta equals the reference's
 //             bit for bit (quick bracketing test, IEEE sqrt and divide only inside the guard band), so the per-body
 //             visit counters are exact; the accepted term m*(xj-x)/dx^3 uses polished v_rsq/v_rcp seeds.
-// Depth limit: MAXL = 21 (3D) / 32 (2D) levels, i.e. bodies closer than root_side/2^MAXL in every coordinate are
-// reported as an error (the reference keeps splitting until its node pool overflows).
+// Key depth: MAXL = 21 (3D) / 32 (2D) levels; cells that still hold >= 2 bodies there are finished level by level by one
+// thread each (ot_build_deep_kernel), so the tree has the reference's shape at any depth.
 #include "common.hpp"
 #include "radix_sort.hpp"
 
@@ -32,7 +32,9 @@ namespace nbody {
 constexpr int kOB            = 256;
 constexpr uint32_t kOtEmpty  = 0xffffffffu;  // src/octree.h:37
 constexpr uint32_t kOtBody   = 0xfffffffeu;  // src/octree.h:38
-constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u;
+constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u;
+constexpr int kOtDeepLevels = 128;  // total depth the deep build follows before it calls the bodies coincident
+constexpr int kOtDeepFrames = 192;  // its DFS stack (one chain of close bodies needs ~2 per level)
 
 template <int D>
 constexpr int kMaxLevels = D == 3 ? 21 : 32;
@@ -202,10 +204,6 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
   const uint32_t rank = base + k;
   const uint32_t fc   = 1u + rank * NCH;  // its sibling group (the reference's bump allocator hands out the same shape)
   bool live           = k < count;        // lane groups of a cell stay together
-  if (live && level >= kMaxLevels<D>) {   // >= 2 bodies share every key digit: deeper than the keys resolve
-    if (c == 0) atomicOr(flags, kFlagDepth);  // the node stays an (empty) leaf; nbody_octree_info reports the error
-    live = false;
-  }
   if (live && fc + NCH > capacity) {
     if (c == 0) atomicOr(flags, kFlagCapacity);
     live = false;
@@ -264,6 +262,144 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
         base + count + block_first + wave_first[wave] + uint32_t(__builtin_popcountll(voters & ((1ull << lane) - 1ull)));
     if (pos < max_cells) cells[pos] = ot_cell{ci, lo, end};
     else atomicOr(flags, kFlagCapacity);
+  }
+}
+
+// ---- cells below the key depth ------------------------------------------------------------------------------------------
+// A cell at depth kMaxLevels still holding >= 2 bodies is finer than the keys resolve.  That is rare in a fresh system and
+// routine in a long run: a few escapers inflate the root cube (side 3*10^4 after 400 steps of the 10^5-body galaxy) until
+// root_side / 2^21 exceeds the spacing of the bodies left in the core.  The reference simply keeps splitting
+// (src/octree.h:127-176), so these cells are finished the reference's way: one thread per cell follows the same
+// `pos > divide` chain level by level, writes the sibling groups and, on the way back up, the monopoles in child order
+// (src/octree.h:205-216).  Groups are numbered after all the breadth-first ones.  Bodies that have not separated after
+// kOtDeepLevels levels are reported as coincident (the reference would split until its node pool overflows).
+template <typename T, int D>
+__device__ uint32_t ot_hyperant_at(const T* __restrict__ x, uint32_t body, const T* __restrict__ root, int level) {
+#pragma clang fp contract(off)
+  T pos[D], divide[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    pos[k]    = x[uint64_t(body) * D + k];
+    divide[k] = root[k];
+  }
+  T side      = root[D];
+  uint32_t cp = 0;
+  for (int l = 0; l <= level; ++l) {  // the chain of ot_keys_kernel, continued to `level`
+    const T half = side / T(4);
+    cp           = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const int gt = pos[k] > divide[k];
+      cp |= uint32_t(gt) << k;
+      divide[k] += T(2 * gt - 1) * half;
+    }
+    side /= T(2);
+  }
+  return cp;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict__ sidx, uint32_t* __restrict__ tmp,
+                                                           const T* __restrict__ m,
+                                                           const T* __restrict__ x, const T* __restrict__ root,
+                                                           ot_node<T>* __restrict__ nodes, const ot_cell* __restrict__ cells,
+                                                           uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ flags,
+                                                           uint32_t capacity) {
+#pragma clang fp contract(off)
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  uint32_t base = 0;  // cells of the levels above = position of the first cell of depth ML
+  for (int j = 0; j < ML; ++j) base += lvl_count[j];
+  const uint32_t count = lvl_count[ML], regular = base + count;
+  struct frame {
+    uint32_t node, s, e;
+    uint32_t rank_level;  // level | done << 31 ; rank of a regular (depth ML) cell is implied by its position
+  };
+  frame stack[kOtDeepFrames];
+  for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+    const ot_cell top = cells[base + k];
+    int sp            = 0;
+    stack[sp++]       = frame{top.node, top.start, top.end, uint32_t(ML)};
+    bool failed       = false;
+    while (sp > 0) {
+      frame f         = stack[sp - 1];
+      const int level = int(f.rank_level & 0x7fffffffu);
+      if (f.rank_level >> 31) {  // second visit: every child cell is finished — this cell's monopole, children in order
+        --sp;
+        const uint32_t fc = nodes[f.node].fc;
+        T mass = T(0), xx[D];
+#pragma unroll
+        for (int q = 0; q < D; ++q) xx[q] = T(0);
+        for (uint32_t c = 0; c < NCH; ++c) {
+          const T cm = nodes[fc + c].m;
+          mass += cm;
+#pragma unroll
+          for (int q = 0; q < D; ++q) xx[q] += cm * nodes[fc + c].p[q];
+        }
+#pragma unroll
+        for (int q = 0; q < D; ++q) nodes[f.node].p[q] = xx[q] / mass;
+        nodes[f.node].m = mass;
+        continue;
+      }
+      // first visit: split [s, e) by the hyperant of this depth
+      if (level >= kOtDeepLevels || failed) {
+        if (!failed) atomicOr(flags, kFlagDepth);
+        failed = true;  // leave the rest of this subtree as (empty) leaves
+        --sp;
+        continue;
+      }
+      const uint32_t rank = f.node == top.node ? base + k : regular + atomicAdd(&lvl_count[ML + 1], 1u);
+      const uint32_t fc   = 1u + rank * NCH;
+      if (fc + NCH > capacity) {
+        atomicOr(flags, kFlagCapacity);
+        failed = true;
+        --sp;
+        continue;
+      }
+      // counting sort of the segment by hyperant, through the sort's idle index buffer (segments of different cells are disjoint)
+      uint32_t bound[NCH + 1];
+      for (uint32_t c = 0; c <= NCH; ++c) bound[c] = 0;
+      for (uint32_t i = f.s; i < f.e; ++i) ++bound[ot_hyperant_at<T, D>(x, sidx[i], root, level) + 1];
+      bound[0] = f.s;
+      for (uint32_t c = 0; c < NCH; ++c) bound[c + 1] += bound[c];
+      {
+        uint32_t next[NCH];
+        for (uint32_t c = 0; c < NCH; ++c) next[c] = bound[c];
+        for (uint32_t i = f.s; i < f.e; ++i) {
+          const uint32_t b = sidx[i];
+          tmp[next[ot_hyperant_at<T, D>(x, b, root, level)]++] = b;
+        }
+        for (uint32_t i = f.s; i < f.e; ++i) sidx[i] = tmp[i];
+      }
+      nodes[f.node].fc      = fc;
+      stack[sp - 1].rank_level = uint32_t(level) | 0x80000000u;  // come back for the monopole
+      for (uint32_t c = 0; c < NCH; ++c) {
+        const uint32_t cnt = bound[c + 1] - bound[c];
+        ot_node<T> r;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) r.p[q] = T(0);
+        r.m   = T(0);
+        r.lvl = uint32_t(level) + 1u;
+        r.fc  = kOtEmpty;
+        if (cnt == 1) {
+          const uint64_t b = sidx[bound[c]];
+#pragma unroll
+          for (int q = 0; q < D; ++q) r.p[q] = x[b * D + q];
+          r.m  = m[b];
+          r.fc = kOtBody;
+        }
+        nodes[fc + c] = r;
+      }
+      for (uint32_t c = NCH; c-- > 0;) {  // children that are cells, last first so that the first is finished first
+        if (bound[c + 1] - bound[c] < 2) continue;
+        if (sp == kOtDeepFrames) {
+          atomicOr(flags, kFlagDepth);
+          failed = true;
+          break;
+        }
+        stack[sp++] = frame{fc + c, bound[c], bound[c + 1], uint32_t(level) + 1u};
+      }
+    }
   }
 }
 
@@ -466,7 +602,7 @@ template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const uint32_t* __restrict__ list,
                                                       uint32_t nlist, const T* __restrict__ x, T* __restrict__ a, T c,
                                                       uint32_t first, T theta, uint32_t capacity, const T* __restrict__ root,
-                                                      uint32_t* __restrict__ counters) {
+                                                      uint32_t* __restrict__ flags, uint32_t* __restrict__ counters) {
   constexpr uint32_t NCH   = 1u << D;
   constexpr uint32_t GPW   = 64u / NCH;                         // bodies per wave
   constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;  // a pop frees one slot, an open adds <= 2^D
@@ -529,6 +665,10 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
     }
     if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2f, y0);
     const uint32_t open_mask = uint32_t((__ballot(!take) >> (g * NCH)) & ((1ull << NCH) - 1ull));
+    if (sp + uint32_t(__builtin_popcount(open_mask)) > DEPTH) {  // only below the key depth can a walk hold this many
+      if (cc == 0) atomicOr(flags, kFlagStack);                  // pending nodes; reported by nbody_octree_info
+      break;
+    }
     if (!take) stack[g][sp + uint32_t(__builtin_popcount(open_mask >> (cc + 1u)))] = nd.fc;  // reverse child order
     sp += uint32_t(__builtin_popcount(open_mask));
     if (sp == 0u) break;
@@ -613,7 +753,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
                      static_cast<const T*>(s->x), nodes, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
-  for (int l = 0; l <= kMaxLevels<D>; ++l) {
+  for (int l = 0; l < kMaxLevels<D>; ++l) {
     const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
     hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l * NCH + kOBuild - 1) / kOBuild)), dim3(kOBuild), 0, st, l,
                        t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), nodes, t->cells,
@@ -621,6 +761,11 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
     NB_HIP(hipGetLastError());
     if (width < (uint64_t(1) << 40)) width *= NCH;
   }
+  // cells still holding >= 2 bodies at the key depth (none in a typical step: the kernel then returns at once)
+  hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
+                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells,
+                     t->lvl_count, flags, t->capacity);
+  NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
 
@@ -660,7 +805,8 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
 #define NB_OT_LAUNCH(CNT)                                                                                                    \
   hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes, list, s->count,                     \
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
-                     static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root), t->counters)
+                     static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root),                                   \
+                     t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
   if (t->counters_on) NB_OT_LAUNCH(true);
   else NB_OT_LAUNCH(false);
 #undef NB_OT_LAUNCH
@@ -811,16 +957,20 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
   const uint32_t flags = lv[maxl + 2];  // set by ANY build since the last call
   if (flags != 0) NB_HIP(hipMemsetAsync(t->lvl_count + (maxl + 2), 0, sizeof(uint32_t), st));
   if (flags & kFlagDepth) {
-    set_error("octree depth limit: at least two bodies share all %d key levels (closer than root_side/2^%d in every coordinate)",
-              maxl, maxl);
+    set_error("octree depth limit: bodies not separated after %d levels (coincident positions, or closer than root_side/2^%d)",
+              kOtDeepLevels, kOtDeepLevels);
     return NBODY_ERR_STATE;
   }
   if (flags & kFlagCapacity) {
     set_error("octree node pool exhausted (capacity %u nodes = System::max_tree_node_size)", t->capacity);
     return NBODY_ERR_STATE;
   }
+  if (flags & kFlagStack) {
+    set_error("octree walk: more pending nodes than the per-body stack holds (a tree far deeper than %d levels)", maxl);
+    return NBODY_ERR_STATE;
+  }
   uint64_t cells = 0;
-  for (int l = 0; l <= maxl; ++l) cells += lv[l];
+  for (int l = 0; l <= maxl + 1; ++l) cells += lv[l];  // breadth-first levels, then the groups of the deep build
   if (tree_size) *tree_size = uint32_t(1 + cells * (1u << t->dim));  // next_free_child_group (src/octree.h:152)
   if (root_mass) memcpy(root_mass, rec + 3 * t->tsz, t->tsz);         // m[0].mass()
   return NBODY_OK;

@@ -93,6 +93,41 @@ def test_octree_deep_and_clustered_trees_vs_oracle(nb, oracle, dtype, dim):
         dev.close()
 
 
+@pytest.mark.parametrize("dtype,dim", [(1, 3), (1, 2), (0, 3)])
+def test_octree_below_the_key_depth_vs_oracle(nb, oracle, dtype, dim):
+    """Cells finer than the 21 (3D) / 32 (2D) key levels — what a long run produces once escapers have inflated the root
+    cube — are finished by the deep build the reference's way: same tree size, root monopole, visit counters, forces."""
+    rng = np.random.default_rng(11 + dim)
+    t = np.float64 if dtype == 1 else np.float32
+    n = 2000                           # pool = 2^dim * n nodes (src/system.h:30): room for the deep chains below
+    x = rng.uniform(-1.0, 1.0, (n, dim))
+    x[0] = 9000.0                      # an escaper: root side ~ 1.8e4, key resolution ~ 1e-2 (3D)
+    x[1] = -9000.0
+    x[100:200] = 0.25 + 2e-4 * rng.standard_normal((100, dim))   # a core far below that resolution
+    if dtype == 1:
+        for k in range(6):             # pairs 1e-7 .. 1e-9 apart: 35 - 45 levels deep
+            x[300 + 2 * k + 1] = x[300 + 2 * k] + 10.0 ** (-7 - k // 2)
+    m = rng.uniform(0.5, 2.0, n)
+    for theta in (0.0, 0.5):
+        hs = nb.HostSystem(dtype, dim, n)
+        hs.m[:], hs.x[:] = m.astype(t), x.astype(t)
+        hs.c, hs.dt = 1.0, 0.01
+        ref = oracle.State(dtype, dim, n)
+        ref.m[:], ref.x[:] = hs.m, hs.x
+        ref.c, ref.dt = hs.c, hs.dt
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.octree.enable_counters(True)
+        dev.octree_force(theta)
+        dev.sync()
+        size, mass = dev.octree.info(dev.stream)
+        ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+        assert osize > 1 + (1 << dim) * 60, "the case is meant to be deep"
+        assert (size, mass) == (osize, omass), (theta, size, osize)
+        assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt), theta
+        assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[dtype], theta
+        dev.close()
+
+
 def test_octree_theta0_equals_all_pairs(nb):
     """theta = 0 never approximates: the walk reaches every body leaf (README.md:122-129)."""
     n = 3000
@@ -153,12 +188,12 @@ def test_octree_shard_windows_and_graph(nb):
 def test_octree_errors(nb):
     hs = nb.HostSystem(1, 3, 4)
     hs.m[:] = 1
-    hs.x[:] = [[0, 0, 0], [1, 1, 1], [1, 1, 1], [2, 0, 1]]  # two coincident bodies: the reference would split forever
+    hs.x[:] = [[0, 0, 0], [1, 1, 1], [1, 1, 1], [2, 0, 1]]  # two coincident bodies: the reference would split until its pool overflows
     hs.c, hs.dt = 1.0, 0.1
     dev = nb.DeviceSystem.from_host(hs)
     dev.octree_force(0.5)
     dev.sync()
-    with pytest.raises(nb.NbodyError, match="depth limit"):
+    with pytest.raises(nb.NbodyError, match="node pool exhausted|depth limit"):
         dev.octree.info(dev.stream)
     # the flag is sticky across builds (a run that replays recorded steps checks once, at the end) and cleared by the report
     hs2 = dev.download()
@@ -166,7 +201,7 @@ def test_octree_errors(nb):
     hs2.x[2] = [1.5, 1.0, 1.25]
     dev.upload(hs2)
     dev.octree_force(0.5)      # good build afterwards
-    with pytest.raises(nb.NbodyError, match="depth limit"):
+    with pytest.raises(nb.NbodyError, match="node pool exhausted|depth limit"):
         dev.octree.info(dev.stream)
     size, mass = dev.octree.info(dev.stream)
     assert size == 1 + 8 * ((size - 1) // 8) and mass == 4.0

@@ -17,9 +17,37 @@ def maxrel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-def _phases(nb, oracle, dtype, dim, wl, n, theta, counts=True, traversal=0):
-    ref = oracle.build_model(dtype, dim, wl, n)
-    dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+def _random_system(nb, oracle, rng, dtype, dim, n):
+    """Clusters at random places and scales (1e-5 .. 1e3), a uniform background, a few far outliers, negative coordinates,
+    masses over three decades: the same arrays for the product and for the oracle."""
+    t = np.float64 if dtype == 1 else np.float32
+    x = rng.uniform(-1.0, 1.0, (n, dim)) * 10.0 ** rng.uniform(-1, 2)
+    pos = 0
+    while pos < n // 2:
+        k = int(rng.integers(1, max(2, n // 4)))
+        x[pos:pos + k] = rng.uniform(-50, 50, dim) + 10.0 ** rng.uniform(-5, 1) * rng.standard_normal((min(k, n - pos), dim))
+        pos += k
+    if n > 8:
+        x[-2:] = rng.uniform(-1, 1, (2, dim)) * 10.0 ** rng.uniform(2, 3.5)
+    m = 10.0 ** rng.uniform(-2, 1, n)
+    hs = nb.HostSystem(dtype, dim, n)
+    hs.m[:], hs.x[:] = m.astype(t), x.astype(t)
+    hs.v[:] = rng.standard_normal((n, dim)).astype(t)
+    hs.c, hs.dt = float(10.0 ** rng.uniform(-4, 0)), 0.01
+    ref = oracle.State(dtype, dim, n)
+    for k in ("m", "x", "v", "a", "ao"):
+        getattr(ref, k)[:] = getattr(hs, k)
+    ref.c, ref.dt = hs.c, hs.dt
+    return hs, ref
+
+
+def _phases(nb, oracle, dtype, dim, wl, n, theta, counts=True, traversal=0, system=None):
+    if system is None:
+        ref = oracle.build_model(dtype, dim, wl, n)
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+    else:
+        hs, ref = system
+        dev = nb.DeviceSystem.from_host(hs)
     st, t = dev.state(), dev.bvh
     t.set_traversal(traversal)
     t.enable_counters(counts)
@@ -57,6 +85,18 @@ def test_bvh_phases_bit_exact(nb, oracle, dtype, dim):
                   ("uniform", 2049), ("galaxy", 10000)):
         for theta in (0.0, 0.5, 1.0):
             _phases(nb, oracle, dtype, dim, wl, n, theta, traversal=1 + (n % 2))  # both K9 forms get covered
+
+
+def test_bvh_randomized_systems_bit_exact(nb, oracle):
+    """Two dozen seeded random systems (clusters over eight decades of scale, outliers, random theta, both precisions and
+    dimensions, both traversal forms): every phase bit-exact, counters bit-exact, force within tolerance."""
+    rng = np.random.default_rng(20240601)
+    for case in range(24):
+        dtype, dim = int(rng.integers(0, 2)), int(rng.integers(2, 4))
+        n = int(rng.integers(2, 3000))
+        theta = float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.4]))
+        _phases(nb, oracle, dtype, dim, None, n, theta, counts=True, traversal=1 + case % 2,
+                system=_random_system(nb, oracle, rng, dtype, dim, n))
 
 
 @pytest.mark.parametrize("dtype", [1, 0])

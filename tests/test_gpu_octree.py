@@ -128,6 +128,36 @@ def test_octree_below_the_key_depth_vs_oracle(nb, oracle, dtype, dim):
         dev.close()
 
 
+def test_octree_randomized_systems_vs_oracle(nb, oracle):
+    """Two dozen seeded random systems (clusters over eight decades of scale, far outliers — i.e. cells below the key depth —,
+    random theta, both precisions and dimensions): tree size, root monopole and counters bit-exact, force within tolerance."""
+    from test_gpu_bvh import _random_system
+    rng = np.random.default_rng(20240602)
+    for case in range(24):
+        dtype, dim = int(rng.integers(0, 2)), int(rng.integers(2, 4))
+        n = int(rng.integers(2, 3000))
+        theta = float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.4]))
+        hs, ref = _random_system(nb, oracle, rng, dtype, dim, n)
+        try:
+            ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+        except RuntimeError:   # the reference's node pool overflows on this one (near-coincident floats): both must fail
+            dev = nb.DeviceSystem.from_host(hs)
+            dev.octree_force(theta)
+            with pytest.raises(nb.NbodyError, match="node pool exhausted|depth limit"):
+                dev.octree.info(dev.stream)
+            dev.close()
+            continue
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.octree.enable_counters(True)
+        dev.octree_force(theta)
+        dev.sync()
+        size, mass = dev.octree.info(dev.stream)
+        assert (size, mass) == (osize, omass), (case, dtype, dim, n, theta, size, osize)
+        assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt), (case, dtype, dim, n, theta)
+        assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[dtype], (case, dtype, dim, n, theta)
+        dev.close()
+
+
 def test_octree_theta0_equals_all_pairs(nb):
     """theta = 0 never approximates: the walk reaches every body leaf (README.md:122-129)."""
     n = 3000

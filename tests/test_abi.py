@@ -19,6 +19,16 @@ def test_header_and_binding_list_agree(nb):
     assert _header_symbols() == sorted(nb.ABI_SYMBOLS)
 
 
+def test_header_is_plain_c_and_cxx():
+    """The boundary is a C ABI: the header must compile as C99 and as C++ with nothing but the standard headers."""
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "nbody_hip.h")
+    for cmd in (["gcc", "-fsyntax-only", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", hdr],
+                ["g++", "-fsyntax-only", "-x", "c++", "-std=c++17", "-Wall", "-Wextra", "-Werror", hdr]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
 def test_library_exports_every_declared_symbol(nb):
     if not os.path.exists(nb.LIB_PATH):
         nb.build()

@@ -101,12 +101,13 @@ def test_two_rank_sharded_equals_single(n, oracle):
     assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
 
 
-def test_two_rank_sharded_octree_equals_single(oracle):
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_octree_equals_single(oracle, world):
     n, steps = 301, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, steps, q, "octree")) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, steps, q, "octree")) for r in range(world)]
     for p in procs:
         p.start()
     x, v, a = q.get(timeout=120)

@@ -602,35 +602,42 @@ __device__ __forceinline__ T ot_dist2_fused(const T (&di)[D]) {
 // Opening test `side / (sqrt(d2) + eps) < theta` (src/octree.h:243, src/vec.h:243-246).  The reference's decision is
 // reproduced bit-for-bit: q = side * rsq(d2) brackets the exact quotient to ~2^-23, so a lane whose q is outside
 // theta*(1 -+ 2^-16) is decided by it; if any lane that `need`s a decision is inside the band (or holds a NaN/inf), the
-// wave evaluates the reference's expression with IEEE sqrt and divide.  y0 = rsq(ot_dist2_fused(di)).
+// wave evaluates the reference's expression with IEEE sqrt and divide.  y0 = rsq(ot_dist2_fused(dj)), dj = xj - x (the
+// exact sum uses the squares only, so the sign convention does not matter to it).
 template <typename T, int D>
-__device__ __forceinline__ bool ot_accept(bool need, T side, const T (&di)[D], T y0, const ot_theta<T>& th) {
-  const T q  = side * y0;                                                 // >= side / (sqrt(d2) + eps), up to the seed error
-  const T ql = __builtin_elementwise_fma(-q, ot_consts<T>::eps * y0, q);  // <= it: 1/(1 + eps/s) >= 1 - eps/s
-  const bool sure_take = q < th.lo, sure_open = ql > th.hi;
+__device__ __forceinline__ bool ot_accept(bool need, T side, const T (&dj)[D], T y0, const ot_theta<T>& th) {
+  const T q = side * y0;  // >= side / (sqrt(d2) + eps), up to the seed error
+  bool sure_take = q < th.lo, sure_open;
+  if constexpr (sizeof(T) == 8) {
+    // the quotient is also >= q * (1 - eps * y0): with y0 < 2^35 that factor differs from 1 by < 2^-17, inside the band
+    sure_open = q > th.hi && y0 < T(0x1p35);
+  } else {
+    const T ql = __builtin_elementwise_fma(-q, ot_consts<T>::eps * y0, q);  // 1/(1 + eps/s) >= 1 - eps/s
+    sure_open  = ql > th.hi;
+  }
   bool take = sure_take;
   if (__ballot(need && !sure_take && !sure_open) != 0ull) {
 #pragma clang fp contract(off)
-    take = side / (ot_sqrt(ot_dist2_exact<T, D>(di)) + ot_consts<T>::eps) < th.exact;
+    take = side / (ot_sqrt(ot_dist2_exact<T, D>(dj)) + ot_consts<T>::eps) < th.exact;
   }
   return take;
 }
 
 // a += mj * (xj - x) / dx^3, dx = sqrt(d2) + eps (src/octree.h:240-241), for the lanes in `on`; tolerance parity: sqrt from
-// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  di = x - xj, d2f = ot_dist2_fused(di),
-// y0 = rsq(d2f).  The body's own leaf and empty leaves add exactly 0 (di == 0 or mj == 0): dx^3 >= eps^3 keeps the
+// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  dj = xj - x, d2f = ot_dist2_fused(dj),
+// y0 = rsq(d2f).  The body's own leaf and empty leaves add exactly 0 (dj == 0 or mj == 0): dx^3 >= eps^3 keeps the
 // weight finite.
 template <typename T, int D>
-__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&di)[D], T mj, T d2f, T y0) {
+__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&dj)[D], T mj, T d2f, T y0) {
 #pragma clang fp contract(off)
   const T t  = d2f * y0;
   const T e  = __builtin_elementwise_fma(-t, y0, T(1));
   const T sq = __builtin_elementwise_fma(T(0.5) * t, e, t);
   const T dx = sq + ot_consts<T>::eps;
   T w        = mj * ot_recip((dx * dx) * dx);
-  w          = on ? -w : T(0);
+  w          = on ? w : T(0);
 #pragma unroll
-  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, di[k], acc[k]);
+  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, dj[k], acc[k]);
 }
 
 // Shard windows.  The walk takes bodies in key order, the window [first, first + count) is a range of BODY indices, so the
@@ -733,7 +740,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
     const ot_node<T> nd = nodes[0];
     T di[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
     const T d2f     = ot_dist2_fused<T, D>(di);
     const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;  // kOtBody or kOtEmpty
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
     const ot_node<T> nd = groups[cur].load(cc);  // this lane's child: two or three 16-/8-byte loads
     T di[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = xi[k] - nd.p[k];
+    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
     const T d2f     = ot_dist2_fused<T, D>(di);
     const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;

@@ -43,9 +43,9 @@ struct ot_cell {  // an internal cell waiting to be split: its node index and it
   uint32_t node, start, end;
 };
 
-// One tree node = one aligned record (64 B f64 / 32 B f32): monopole (src/octree.h:55-56 `m`), first child
-// (src/octree.h:52) and depth.  The side of a node's cell is root_side * 2^-lvl EXACTLY — the reference halves a running
-// value while it descends (src/octree.h:245), and power-of-two scaling is exact — so it is not stored: a visit reads 40 B.
+// One tree node: monopole (src/octree.h:55-56 `m`), first child (src/octree.h:52) and depth.  The side of a node's cell
+// is root_side * 2^-lvl EXACTLY — the reference halves a running value while it descends (src/octree.h:245), and
+// power-of-two scaling is exact — so it is not stored: a visit reads 40 B.  In memory only the root has this shape.
 template <typename T>
 struct alignas(8 * sizeof(T)) ot_node {
   T p[3];
@@ -143,6 +143,31 @@ struct alignas(64) ot_group<double, 2> {
     nd.fc   = f.x;
     nd.lvl  = f.y;
     return nd;
+  }
+};
+
+// The tree as the kernels see it: node 0 (the root) is a record of its own, node 1 + g * 2^D + c is child slot c of sibling
+// group g.  Build-side code thinks in node indices (fc = index of the first child, as in the reference); the stored fc of a
+// cell is its child GROUP number, which is what the walk wants.
+template <typename T, int D>
+struct ot_tree {
+  static constexpr uint32_t NCH = 1u << D;
+  ot_group<T, D>* groups;
+  ot_node<T>* root;
+  __device__ ot_node<T> get(uint32_t idx) const {
+    ot_node<T> nd = idx == 0 ? *root : groups[(idx - 1u) / NCH].load((idx - 1u) % NCH);
+    if (nd.fc < kOtBody) nd.fc = 1u + nd.fc * NCH;
+    return nd;
+  }
+  __device__ void put(uint32_t idx, const ot_node<T>& nd) const {
+    const uint32_t stored_fc = nd.fc < kOtBody ? (nd.fc - 1u) / NCH : nd.fc;
+    if (idx == 0) {
+      ot_node<T> r = nd;
+      r.fc         = stored_fc;
+      *root        = r;
+    } else {
+      groups[(idx - 1u) / NCH].store((idx - 1u) % NCH, nd, stored_fc);
+    }
   }
 };
 
@@ -248,7 +273,7 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
 
 // ---- breadth-first build --------------------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
+__global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, ot_tree<T, D> tree,
                                      ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
   if (threadIdx.x == 0) {  // (the overflow flags behind lvl_count are sticky: nbody_octree_info reports and clears them)
@@ -267,7 +292,7 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
       r.m  = m[0];
       r.fc = kOtBody;
     }
-    nodes[0] = r;
+    tree.put(0, r);
   }
 }
 
@@ -280,7 +305,7 @@ constexpr int kOBuild = 1024;
 template <typename T, int D>
 __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
                                                                  const uint32_t* __restrict__ sidx, const T* __restrict__ m,
-                                                                 const T* __restrict__ x, ot_node<T>* __restrict__ nodes,
+                                                                 const T* __restrict__ x, ot_tree<T, D> tree,
                                                                  ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
                                                                  uint32_t* __restrict__ flags, uint32_t capacity,
                                                                  uint32_t max_cells) {
@@ -330,8 +355,12 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
       r.m  = m[b];
       r.fc = kOtBody;
     }
-    nodes[ci] = r;
-    if (c == 0) nodes[cell.node].fc = fc;
+    tree.put(ci, r);
+    if (c == 0) {
+      ot_node<T> pn = tree.get(cell.node);
+      pn.fc         = fc;
+      tree.put(cell.node, pn);
+    }
   }
   // children holding >= 2 bodies are split on the next level (which sets their fc)
   const bool split      = live && end - lo >= 2;
@@ -394,7 +423,7 @@ template <typename T, int D>
 __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict__ sidx, uint32_t* __restrict__ tmp,
                                                            const T* __restrict__ m,
                                                            const T* __restrict__ x, const T* __restrict__ root,
-                                                           ot_node<T>* __restrict__ nodes, const ot_cell* __restrict__ cells,
+                                                           ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
                                                            uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ flags,
                                                            uint32_t capacity) {
 #pragma clang fp contract(off)
@@ -418,19 +447,20 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
       const int level = int(f.rank_level & 0x7fffffffu);
       if (f.rank_level >> 31) {  // second visit: every child cell is finished — this cell's monopole, children in order
         --sp;
-        const uint32_t fc = nodes[f.node].fc;
+        ot_node<T> pn = tree.get(f.node);
         T mass = T(0), xx[D];
 #pragma unroll
         for (int q = 0; q < D; ++q) xx[q] = T(0);
         for (uint32_t c = 0; c < NCH; ++c) {
-          const T cm = nodes[fc + c].m;
-          mass += cm;
+          const ot_node<T> ch = tree.get(pn.fc + c);
+          mass += ch.m;
 #pragma unroll
-          for (int q = 0; q < D; ++q) xx[q] += cm * nodes[fc + c].p[q];
+          for (int q = 0; q < D; ++q) xx[q] += ch.m * ch.p[q];
         }
 #pragma unroll
-        for (int q = 0; q < D; ++q) nodes[f.node].p[q] = xx[q] / mass;
-        nodes[f.node].m = mass;
+        for (int q = 0; q < D; ++q) pn.p[q] = xx[q] / mass;
+        pn.m = mass;
+        tree.put(f.node, pn);
         continue;
       }
       // first visit: split [s, e) by the hyperant of this depth
@@ -463,7 +493,11 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
         }
         for (uint32_t i = f.s; i < f.e; ++i) sidx[i] = tmp[i];
       }
-      nodes[f.node].fc      = fc;
+      {
+        ot_node<T> pn = tree.get(f.node);
+        pn.fc         = fc;
+        tree.put(f.node, pn);
+      }
       stack[sp - 1].rank_level = uint32_t(level) | 0x80000000u;  // come back for the monopole
       for (uint32_t c = 0; c < NCH; ++c) {
         const uint32_t cnt = bound[c + 1] - bound[c];
@@ -480,7 +514,7 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
           r.m  = m[b];
           r.fc = kOtBody;
         }
-        nodes[fc + c] = r;
+        tree.put(fc + c, r);
       }
       for (uint32_t c = NCH; c-- > 0;) {  // children that are cells, last first so that the first is finished first
         if (bound[c + 1] - bound[c] < 2) continue;
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
 
 // ---- multipoles (src/octree.h:205-216) ---------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_node<T>* __restrict__ nodes,
+__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_tree<T, D> tree,
                                                                  const ot_cell* __restrict__ cells,
                                                                  const uint32_t* __restrict__ lvl_count) {
 #pragma clang fp contract(off)
@@ -508,33 +542,22 @@ __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_n
   uint32_t base = 0;
   for (int j = 0; j < level; ++j) base += lvl_count[j];
   const uint32_t node = cells[base + k].node;
-  const uint32_t fc   = nodes[node].fc;
+  ot_node<T> pn       = tree.get(node);
+  const uint32_t fc   = pn.fc;
   if (fc == kOtEmpty || fc == kOtBody) return;  // only after an overflow flag
   T mass = T(0), xx[D];
 #pragma unroll
   for (int q = 0; q < D; ++q) xx[q] = T(0);
   for (uint32_t c = 0; c < NCH; ++c) {  // child order; empty children add (0, 0)
-    const T cm = nodes[fc + c].m;
-    mass += cm;
+    const ot_node<T> ch = tree.get(fc + c);
+    mass += ch.m;
 #pragma unroll
-    for (int q = 0; q < D; ++q) xx[q] += cm * nodes[fc + c].p[q];
+    for (int q = 0; q < D; ++q) xx[q] += ch.m * ch.p[q];
   }
 #pragma unroll
-  for (int q = 0; q < D; ++q) nodes[node].p[q] = xx[q] / mass;
-  nodes[node].m = mass;
-}
-
-// ---- regrouping for the walk -------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_pack_groups_kernel(const ot_node<T>* __restrict__ nodes, ot_group<T, D>* __restrict__ groups,
-                                                             const uint32_t* __restrict__ lvl_count, uint32_t capacity) {
-  constexpr uint32_t NCH = 1u << D;
-  uint32_t cells = 0;  // cells of every level + the groups of the deep build = sibling groups in use
-  for (int j = 0; j <= kMaxLevels<D> + 1; ++j) cells += lvl_count[j];
-  const uint32_t idx = 1u + blockIdx.x * kOB + threadIdx.x;
-  if (idx >= 1u + cells * NCH || idx >= capacity) return;
-  const ot_node<T> nd = nodes[idx];
-  groups[(idx - 1u) / NCH].store((idx - 1u) % NCH, nd, nd.fc >= kOtBody ? nd.fc : (nd.fc - 1u) / NCH);
+  for (int q = 0; q < D; ++q) pn.p[q] = xx[q] / mass;
+  pn.m = mass;
+  tree.put(node, pn);
 }
 
 // ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------
@@ -711,7 +734,7 @@ __global__ __launch_bounds__(kOC) void ot_owned_scatter_kernel(const uint32_t* _
 // (tolerance parity), the set of tests, accepted terms and therefore the counters do not, and the result of a body
 // depends on nothing but the tree and that body (so it is independent of the shard window).
 template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ nodes, const ot_group<T, D>* __restrict__ groups,
+__global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restrict__ rootrec, const ot_group<T, D>* __restrict__ groups,
                                                       const uint32_t* __restrict__ list,
                                                       uint32_t nlist, const T* __restrict__ x, T* __restrict__ a, T c,
                                                       uint32_t first, T theta, uint32_t capacity, const T* __restrict__ root,
@@ -737,7 +760,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   uint32_t cur = 0, sp = 0;
   bool more = false;
   if (valid) {  // the root is examined alone (by every lane of the group; lane 0 keeps the result)
-    const ot_node<T> nd = nodes[0];
+    const ot_node<T> nd = *rootrec;
     T di[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
@@ -751,7 +774,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
       c_terms = take;
     }
     more = !take;
-    cur  = (nd.fc - 1u) / NCH;  // from here on `cur` is a sibling-group number
+    cur  = nd.fc;  // the root's stored fc is already a sibling-group number, like every fl[][0] below
   }
   uint32_t guard = capacity;  // a well-formed tree is left after < capacity steps; never spin on a damaged one
   while (more && guard-- != 0u) {  // the lanes of a group leave together
@@ -810,8 +833,8 @@ struct nbody_octree {
   uint64_t* keys[2] = {nullptr, nullptr};
   uint32_t* idx[2]  = {nullptr, nullptr};
   uint32_t* hist   = nullptr;
-  void* nodes      = nullptr;  // ot_node<T>[capacity]
-  void* groups     = nullptr;  // ot_group<T,D>[max_cells]: the walk's copy
+  void* rootrec    = nullptr;  // ot_node<T>: node 0
+  void* groups     = nullptr;  // ot_group<T,D>[max_cells]: sibling group g = nodes 1 + g * 2^D ...
   size_t group_bytes = 0;
   nbody::ot_cell* cells = nullptr;
   uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
@@ -847,7 +870,7 @@ template <typename T, int D>
 static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
   const uint32_t n       = s->sz;
-  auto* nodes            = static_cast<ot_node<T>*>(t->nodes);
+  const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
   hipLaunchKernelGGL((ot_keys_kernel<T, D>), dim3((n + kOB - 1) / kOB), dim3(kOB), 0, st, static_cast<const T*>(s->x), n,
                      static_cast<const T*>(t->root), t->keys[0]);
   NB_HIP(hipGetLastError());
@@ -856,20 +879,20 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   t->sorted_buf = fin;
   uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), nodes, t->cells, t->lvl_count);
+                     static_cast<const T*>(s->x), tree, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
   uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
   for (int l = 0; l < kMaxLevels<D>; ++l) {
     const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
     hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l * NCH + kOBuild - 1) / kOBuild)), dim3(kOBuild), 0, st, l,
-                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), nodes, t->cells,
+                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->cells,
                        t->lvl_count, flags, t->capacity, t->max_cells);
     NB_HIP(hipGetLastError());
     if (width < (uint64_t(1) << 40)) width *= NCH;
   }
   // cells still holding >= 2 bodies at the key depth (none in a typical step: the kernel then returns at once)
   hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
-                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), nodes, t->cells,
+                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), tree, t->cells,
                      t->lvl_count, flags, t->capacity);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
@@ -878,18 +901,15 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
 template <typename T, int D>
 static int ot_tree_run(nbody_octree* t, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
-  auto* nodes            = static_cast<ot_node<T>*>(t->nodes);
+  const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
   for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
     uint64_t width = 1;
     for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
     const uint64_t cap_l = width < uint64_t(t->n / 2 + 1) ? width : uint64_t(t->n / 2 + 1);
     hipLaunchKernelGGL((ot_multipole_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
-                       nodes, t->cells, t->lvl_count);
+                       tree, t->cells, t->lvl_count);
     NB_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL((ot_pack_groups_kernel<T, D>), dim3((t->capacity + kOB - 1) / kOB), dim3(kOB), 0, st, nodes,
-                     static_cast<ot_group<T, D>*>(t->groups), t->lvl_count, t->capacity);
-  NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
 
@@ -910,9 +930,9 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
   }
   const uint32_t per_wave = 64u >> D;
   const uint32_t blocks   = (s->count + per_wave - 1) / per_wave;
-  auto* nodes             = static_cast<const ot_node<T>*>(t->nodes);
+  auto* rootrec           = static_cast<const ot_node<T>*>(t->rootrec);
 #define NB_OT_LAUNCH(CNT)                                                                                                    \
-  hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, nodes,                                     \
+  hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, rootrec,                                   \
                      static_cast<const ot_group<T, D>*>(t->groups), list, s->count,                                          \
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
                      static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root),                                   \
@@ -961,7 +981,7 @@ extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint3
   NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(radix_sort_blocks(n)) + 1));
-  NB_ALLOC(t->nodes, t->tsz * 8 * size_t(t->capacity));
+  NB_ALLOC(t->rootrec, 64);
   t->group_bytes = dtype == NBODY_F32 ? (dim == 3 ? sizeof(ot_group<float, 3>) : sizeof(ot_group<float, 2>))
                                       : (dim == 3 ? sizeof(ot_group<double, 3>) : sizeof(ot_group<double, 2>));
   NB_ALLOC(t->groups, t->group_bytes * size_t(t->max_cells));
@@ -982,7 +1002,7 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
   (void)hipFree(t->idx[0]);
   (void)hipFree(t->idx[1]);
   (void)hipFree(t->hist);
-  (void)hipFree(t->nodes);
+  (void)hipFree(t->rootrec);
   (void)hipFree(t->groups);
   (void)hipFree(t->cells);
   (void)hipFree(t->lvl_count);
@@ -1066,7 +1086,7 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
   uint32_t lv[40];
   NB_HIP(hipMemcpyAsync(lv, t->lvl_count, sizeof(uint32_t) * (maxl + 3), hipMemcpyDeviceToHost, st));
   char rec[32];
-  NB_HIP(hipMemcpyAsync(rec, t->nodes, t->tsz * 4, hipMemcpyDeviceToHost, st));
+  NB_HIP(hipMemcpyAsync(rec, t->rootrec, t->tsz * 4, hipMemcpyDeviceToHost, st));
   NB_HIP(hipStreamSynchronize(st));
   const uint32_t flags = lv[maxl + 2];  // set by ANY build since the last call
   if (flags != 0) NB_HIP(hipMemsetAsync(t->lvl_count + (maxl + 2), 0, sizeof(uint32_t), st));

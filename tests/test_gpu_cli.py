@@ -193,3 +193,17 @@ def test_call_sequence_and_shard_errors(nb):
         dev.all_pairs_force(90, 20)
     with pytest.raises(nb.NbodyError):
         nb.Bvh(1, 3, 1)  # the reference's tree needs at least one body pair
+
+
+def test_abi_from_plain_c(tmp_path):
+    """examples/abi_from_c.c: the boundary used from C99 with nothing but include/nbody_hip.h and -lnbody_hip."""
+    import subprocess
+    exe = str(tmp_path / "abi_from_c")
+    libdir = os.path.join(ROOT, "stdpar-nbody_amd")
+    build = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                            os.path.join(ROOT, "examples", "abi_from_c.c"), "-L" + libdir, "-lnbody_hip", "-Wl,-rpath," + libdir, "-lm",
+                            "-o", exe], capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tree size" in r.stdout and "root mass" in r.stdout

@@ -2,19 +2,22 @@
 """Headline benchmark: body-steps/s (+ % of gfx950 FP64 vector peak) for 3D double all-pairs on the
 synthetic galaxy init, N = 2^20 bodies, on 1/2/4/8 MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (any N: for N > 1 it starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W            (the driver's form: runs as one of the ranks)
 
 One process per GPU.  A "step" is one pass of the hot path over all bodies: K1 all-pairs force on the
 rank's shard of targets (all N sources), K3 leapfrog on the shard, then one RCCL all-gather of the
-updated positions over xGMI (torch.distributed, backend "nccl").  Total work is fixed as N grows
+updated positions over xGMI (nbody_allgather_positions of the C ABI; torch.distributed, backend "nccl", carries the
+rendezvous, the barriers and the max-over-ranks of the time).  Total work is fixed as N grows
 (strong scaling).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 PyTorch is plumbing here (device memory, streams, the process group); all arithmetic is in
 stdpar-nbody_amd/libnbody_hip.so through its C ABI.  The CPU baseline leg times the oracle's
 restatement of the reference loop on this box's host cores (reported, not the target).
 """
+import os
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before any HIP runtime is loaded: dmabuf IPC only on this driver
 import argparse
 import ctypes as C
 import importlib.util
@@ -135,6 +138,85 @@ class Telemetry:
                 "socket_power_w_mean": sum(pw) / len(pw) if pw else None}
 
 
+def k1_source_sha():
+    """Identity of the K1 kernel source: profiles are stamped with it, and evidence taken from another source is dropped."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("all_pairs.hip", "common.hpp"):
+        h.update(open(os.path.join(ROOT, "stdpar-nbody_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_evidence(world, n, kernel_desc):
+    """(traffic bytes per launch, rocprof evidence dict) from the newest committed PMC summary under profiles/ whose stamp —
+    kernel description string and source hash — matches what THIS run launches; (None, None) otherwise.  rocprofv3 counters
+    cannot be collected from inside the timed run; what can be done is to refuse numbers taken with a different kernel."""
+    import glob
+    sha = k1_source_sha()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "bench_n1_pmc_all_pairs_force.json")), reverse=True):
+        try:
+            c = json.load(open(path))
+        except Exception:
+            continue
+        if c.get("n") != n or c.get("gpus") != world or c.get("kernel") != kernel_desc or c.get("source_sha") != sha:
+            continue
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                        # summed over the 8 XCDs
+        prof_s = c["duration_ns_pmc_sq"] * 1e-9                    # kernel duration inside the profiled pass
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0  # KB; FETCH_SIZE doubled on gfx950 (MI355X_MICROARCH.md)
+        rel = os.path.relpath(path, ROOT)
+        return traffic, {
+            "source": rel + " (rocprofv3 --pmc, separate passes; stamped with this kernel and source hash)",
+            "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024),   # quad-cycles -> cycles, 1024 SIMDs
+            "valu_insts_per_wave_pair": c["SQ_INSTS_VALU"] / (n * n / 64.0),
+            "effective_clock_ghz": cycles / prof_s / 1e9,
+            "hbm_gbps": traffic / prof_s / 1e9, "hbm_peak_gbps": 8000.0,
+        }
+    return None, None
+
+
+def visible_gpus():
+    """Number of HIP devices this process could use, without creating a HIP context (torch.cuda.device_count() reads the
+    driver's device list only)."""
+    import torch
+    return torch.cuda.device_count()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` as typed: this parent never touches a GPU; it starts N fresh rank processes through
+    torch.distributed.run (one per GPU, RCCL rendezvous on 127.0.0.1), relays rank 0's single JSON line to stdout and
+    everything else to stderr, and exits with the launcher's status."""
+    import socket
+    have = visible_gpus()
+    if have < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible to this process")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env["NBODY_BENCH_CHILD"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--bodies", str(args.n)]
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:
+        txt = out.strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
+    raise SystemExit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +226,12 @@ def main():
                     help="bodies (default 2^20, the BASELINE.json metric config); `--n` would collide with torchrun option prefixes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    force_dist = os.environ.get("NBODY_BENCH_FORCE_DIST") == "1"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_dist):
+        launch_ranks(args)  # does not return
 
     # stdout carries exactly ONE line, the JSON: everything else written to fd 1 by this process or its libraries (RCCL
     # prints a version banner there when a communicator is created) goes to stderr until the line is printed
@@ -159,32 +247,41 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus {args.gpus}` (self-launching) "
+                         f"or with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # NBODY_BENCH_FORCE_DIST=1 exercises the RCCL path (init, barrier, all-gather, max-reduce) even with one rank
-    use_dist = world > 1 or os.environ.get("NBODY_BENCH_FORCE_DIST") == "1"
+    # NBODY_BENCH_FORCE_DIST=1 exercises the whole multi-rank path (launcher, process group, communicator, barrier,
+    # all-gather, max-reduce) even with one rank
+    use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nb = load_package()
     par = nb.parallel
 
+    # the data-path collective is the library's own (nbody_allgather_positions, RCCL behind the C ABI); torch.distributed
+    # is the launcher's side: it carries the RCCL unique id to the ranks, the barriers and the max-over-ranks of the time
+    comm = None
+    if use_dist:
+        box = [nb.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm = nb.Comm(world, rank, box[0], local_rank)
+
     # synthetic galaxy init with the product's host generator (host/models.hpp == src/models.h:112-136)
     hs = nb.build_model(nb.F64, 3, "galaxy", args.n)
     n = hs.n
-    sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev, force_exchange=use_dist)
-
-    def step():
-        sim.step()
+    sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev, force_exchange=use_dist, comm=comm)
+    kernel_desc = nb.describe_all_pairs(sim.state())
 
     for _ in range(args.warmup):
-        step()
+        sim.step()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -192,11 +289,12 @@ def main():
     if telemetry:
         telemetry.__enter__()
     t0 = time.perf_counter()
-    force_events = []
+    force_events, xchg_events = [], []
     for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        sim.step(force_events=(e0, e1))
-        force_events.append((e0, e1))
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        sim.step(force_events=(ev[0], ev[1]), exchange_events=(ev[2], ev[3]))
+        force_events.append((ev[0], ev[1]))
+        xchg_events.append((ev[2], ev[3]))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -208,36 +306,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: K1.  Algorithmic flops per launch = 20 x (targets of this rank) x (n - 1)
+    # dominant kernel: K1.  Algorithmic flops per launch = 20 x (targets of this rank) x (n - 1).  HIP events on the stream
+    # the kernels are launched on (torch's current stream is handed to the C ABI).
     k1_ms = sum(a.elapsed_time(b) for a, b in force_events) / max(1, len(force_events))
+    xchg_ms = sum(a.elapsed_time(b) for a, b in xchg_events) / max(1, len(xchg_events))
     flops_per_launch = FLOP_PER_INTERACTION * sim.count * (n - 1)
     achieved = flops_per_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
 
     if rank == 0:
         value = n * args.steps / elapsed
         whole_job_tflops = FLOP_PER_INTERACTION * n * (n - 1) * args.steps / elapsed / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
-        if os.path.exists(pmc):
-            rec = json.load(open(pmc))
-            if rec.get("n") == n and rec.get("gpus") == world:
-                traffic = rec.get("bytes_per_launch")
-        # rocprofv3 evidence for the dominant kernel (north_star: VALU-busy and HBM GB/s against the chip's peak),
-        # derived from the committed PMC passes of this same command (profiles/r01/, tools/profile_bench.sh) — not live
-        evidence = None
-        pmc_path = os.path.join(ROOT, "profiles", "r01", "bench_n1_pmc_all_pairs_force.json")
-        if world == 1 and n == (1 << 20) and os.path.exists(pmc_path):
-            c = json.load(open(pmc_path))
-            cycles = c["GRBM_GUI_ACTIVE"] / 8.0                       # summed over the 8 XCDs
-            prof_s = c.get("duration_ns_pmc_sq", k1_ms * 1e6) * 1e-9  # kernel duration inside the profiled pass
-            evidence = {
-                "source": "profiles/r01/bench_n1_pmc_all_pairs_force.json (rocprofv3 --pmc, separate passes)",
-                "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024),   # quad-cycles -> cycles, 1024 SIMDs
-                "valu_insts_per_wave_pair": c["SQ_INSTS_VALU"] / (n * n / 64.0),
-                "effective_clock_ghz": cycles / prof_s / 1e9,
-                "hbm_gbps": traffic / prof_s / 1e9 if traffic else None, "hbm_peak_gbps": 8000.0,
-            }
+        traffic, evidence = committed_evidence(world, n, kernel_desc)
         tele = telemetry.summary() if telemetry else None
+        row = 3 * 8  # bytes of one position record (3D double)
         out = {
             "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
             "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -247,16 +328,24 @@ def main():
                        "parallelism": "bodies sharded over %d GPU(s), RCCL all-gather(x) per step" % world if world > 1
                        else "single GPU", "split": sim.describe()},
             "pct_fp64_peak": 100.0 * whole_job_tflops / (FP64_VECTOR_PEAK_TFLOPS * world),
+            "rccl_world": ({"world": dist.get_world_size(), "backend": dist.get_backend(),
+                            "data_path": "nbody_comm (ncclCommInitRank) world %d, RCCL %d" % (comm.world, nb.Comm.rccl_version())}
+                           if use_dist else None),
+            "shards": [e - f for f, e in sim.shards],
+            "allgather": {"sent_bytes_per_rank_per_step": sim.count * row, "gathered_bytes_per_step": n * row,
+                          "avg_ms": xchg_ms if use_dist else None,
+                          "how": sim.describe().split("exchange: ")[-1] if use_dist else "none (single GPU, no exchange)"},
             "gpu_telemetry": tele,
-            "roofline": {"bound": "valu_fp64", "kernel": "all_pairs_force_sgpr_kernel<double,3>", "achieved": achieved,
+            "roofline": {"bound": "valu_fp64", "kernel": kernel_desc, "achieved": achieved,
                          "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                         "traffic": traffic, "avg_launch_ms": k1_ms,
+                         "traffic": traffic, "avg_launch_ms": k1_ms, "source_sha": k1_source_sha(),
                          # the same fraction against the peak at the shader clock the box sustained (socket-power capped)
                          "frac_at_measured_clock": (achieved / (FP64_VECTOR_PEAK_TFLOPS * tele["sclk_mhz_mean"] / 2400.0)
                                                     if tele else None),
                          "rocprof": evidence,
                          "note": "north_star forbids MFMA for this path; bound is the FP64 vector pipe "
-                                 "(20 algorithmic flop per ordered pair, SURVEY 8d)"},
+                                 "(20 algorithmic flop per ordered pair, SURVEY 8d); traffic/rocprof are null unless a "
+                                 "committed PMC summary carries this run's kernel description and source hash"},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
@@ -267,6 +356,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

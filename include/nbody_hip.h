@@ -21,6 +21,9 @@
  *    always hold ALL sz bodies (sources); v, a, ao hold `count` records, record k = body first+k.
  *    Single GPU: first = 0, count = sz.
  *  - The library never falls back to a CPU path: without a usable HIP device every call fails.
+ *  - Devices: a context, a tree and a communicator remember the device they were created on; a phase call runs on
+ *    the device of its `stream` (NULL stream: the calling thread's current device).  Every entry point switches to
+ *    that device for the duration of the call and restores the caller's, so one host thread can drive several GPUs.
  */
 #ifndef NBODY_HIP_H
 #define NBODY_HIP_H
@@ -54,10 +57,18 @@ typedef struct nbody_state {
   uint32_t count;  /* number of owned bodies                                        */
   int32_t dtype;   /* NBODY_F32 | NBODY_F64                                         */
   int32_t dim;     /* 2 | 3                                                         */
+  uint32_t tuning; /* K1 launch shape for calls with this view: 0 = the library default, else
+                      NBODY_TUNING(split, targets_per_thread, source_path); never changes which
+                      pairs are summed (see nbody_all_pairs_configure)              */
 } nbody_state;
 
-/* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major. */
-#define NBODY_HIP_ABI_VERSION 1001
+/* split in bits 0-3, targets per lane in bits 4-5, source path in bits 6-7; each 0 = auto */
+#define NBODY_TUNING(split, targets_per_thread, source_path) \
+  ((uint32_t)(((split) & 15) | (((targets_per_thread) & 3) << 4) | (((source_path) & 3) << 6) | 0x100u))
+
+/* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major.
+ * 2.0: nbody_state.tuning; the collective (nbody_comm_*), shard windows on contexts, per-device guards. */
+#define NBODY_HIP_ABI_VERSION 2000
 int nbody_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -95,6 +106,8 @@ int nbody_calc_energies(const nbody_state* s, void* kinetic_out, void* potential
  * 4, 8 (8: scalar-stream form only)}; targets_per_thread in {0 (auto), 1, 2} (no effect on the result).  The auto split
  * depends on sz only — never on first/count — so results are bitwise independent of how bodies are sharded over GPUs. */
 int nbody_all_pairs_configure(int split, int targets_per_thread);
+/* The two calls here set the PROCESS-WIDE default (atomic; used by every view whose `tuning` is 0).  A context carries its
+ * own choice: nbody_ctx_configure_all_pairs stores it and nbody_ctx_state hands it out in nbody_state.tuning. */
 /* How K1 brings a source record to the 64 lanes of a wave (same arithmetic, same order, bitwise the same result):
  * 1 = tiles staged in LDS, read as LDS broadcasts; 2 = records packed once per call and streamed through the scalar
  * unit into SGPRs; 0 = auto (2 once the call has several waves per SIMD, about 65 536 targets; 1 below).  Form 2 keeps a packed-source buffer per calling stream (32 B per body, grow-only):
@@ -187,6 +200,38 @@ int  nbody_ctx_state(nbody_ctx* ctx, nbody_state* out);
 void* nbody_ctx_stream(nbody_ctx* ctx);
 /* Blocks until all work queued on `stream` has completed (so wall-clock phase timers are honest). */
 int  nbody_stream_sync(void* stream);
+/* K1 launch shape of THIS context (0 = auto for each; see nbody_all_pairs_configure / nbody_all_pairs_source_path). */
+int  nbody_ctx_configure_all_pairs(nbody_ctx* ctx, int split, int targets_per_thread, int source_path);
+/* Multi-GPU all-pairs: this context owns target bodies [first, first+count) of the n it was created for.  m and x stay
+ * whole (sources); nbody_ctx_state then returns the window with v/a/ao pointing at the owned rows, and nbody_download
+ * writes only the owned rows of x, v, a, ao (at their place in the full-size host arrays) plus all of m. */
+int  nbody_ctx_set_shard(nbody_ctx* ctx, uint32_t first, uint32_t count);
+/* What K1 will launch for this view, e.g. "all_pairs_force_sgpr_kernel<double,3,R=2,JS=8> tile=512 pair=far3/near2"
+ * (bench.py stamps its profiles with it). */
+int  nbody_all_pairs_describe(const nbody_state* s, char* out, size_t len);
+
+/* ---- the collective: per-step all-gather of position shards (multi-GPU all-pairs; no reference counterpart) ------
+ * RCCL over xGMI.  Partition fixed by the ABI: rank r of W owns bodies [sz*r/W, sz*(r+1)/W) (nbody_shard_range).
+ * Every rank holds all of x; nbody_allgather_positions fills in the other ranks' rows in place, asynchronously on
+ * `stream` (stream-ordered after the K3 that moved the owned rows): one in-place ncclAllGather when W divides sz,
+ * else one grouped ncclSend/ncclRecv per peer.  RCCL is loaded on first use (dlopen), never at library load.
+ *  - one process per GPU: rank 0 calls nbody_comm_get_unique_id, the launcher hands the NBODY_COMM_ID_BYTES to every
+ *    rank (bench.py: torch.distributed broadcast), each rank calls nbody_comm_create;
+ *  - one process, several GPUs (the CLI's --gpus N): nbody_comm_create_all (ncclCommInitAll); the host thread brackets
+ *    the per-device nbody_allgather_positions calls of a step with nbody_comm_group_begin/end. */
+typedef struct nbody_comm nbody_comm;
+#define NBODY_COMM_ID_BYTES 128
+int  nbody_comm_get_unique_id(void* id_out);
+int  nbody_comm_create(nbody_comm** out, int world, int rank, const void* unique_id, int device);
+int  nbody_comm_create_all(nbody_comm** out /* [ndev] */, int ndev, const int* devices /* NULL = 0..ndev-1 */);
+void nbody_comm_destroy(nbody_comm* comm);
+int  nbody_comm_world(const nbody_comm* comm);
+int  nbody_comm_rank(const nbody_comm* comm);
+int  nbody_comm_rccl_version(void); /* ncclGetVersion code, 0 if RCCL cannot be loaded */
+void nbody_shard_range(uint32_t sz, int world, int rank, uint32_t* first, uint32_t* count);
+int  nbody_comm_group_begin(void);
+int  nbody_comm_group_end(void);
+int  nbody_allgather_positions(nbody_comm* comm, const nbody_state* s, void* stream);
 
 /* ---- step graphs ----------------------------------------------------------------------------------------
  * A simulation step is a fixed sequence of phase calls (5 launches for all-pairs, ~40 for bvh).  Between

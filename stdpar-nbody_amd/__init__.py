@@ -32,7 +32,7 @@ class nbody_state(C.Structure):
     """include/nbody_hip.h: device-pointer mirror of System<T,N>::state_t (src/system.h:41-50)."""
     _fields_ = [("m", C.c_void_p), ("x", C.c_void_p), ("v", C.c_void_p), ("a", C.c_void_p), ("ao", C.c_void_p),
                 ("dt", C.c_double), ("c", C.c_double), ("sz", C.c_uint32), ("first", C.c_uint32), ("count", C.c_uint32),
-                ("dtype", C.c_int32), ("dim", C.c_int32)]
+                ("dtype", C.c_int32), ("dim", C.c_int32), ("tuning", C.c_uint32)]
 
 
 def build(verbose=False):
@@ -51,7 +51,13 @@ ABI_SYMBOLS = [
     "nbody_octree_read_counters", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
     "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
+    "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
+    "nbody_comm_get_unique_id", "nbody_comm_create", "nbody_comm_create_all", "nbody_comm_destroy", "nbody_comm_world",
+    "nbody_comm_rank", "nbody_comm_rccl_version", "nbody_shard_range", "nbody_comm_group_begin", "nbody_comm_group_end",
+    "nbody_allgather_positions",
 ]
+ABI_MAJOR = 2
+COMM_ID_BYTES = 128
 
 _lib = None
 _host = None
@@ -72,11 +78,12 @@ def lib():
             except ImportError:
                 pass
         L = C.CDLL(LIB_PATH)
-        if L.nbody_abi_version() // 1000 != 1:
-            raise NbodyError(f"{LIB_PATH} has ABI version {L.nbody_abi_version()}, this binding needs major version 1")
+        if L.nbody_abi_version() // 1000 != ABI_MAJOR:
+            raise NbodyError(f"{LIB_PATH} has ABI version {L.nbody_abi_version()}, this binding needs major version {ABI_MAJOR}")
         L.nbody_last_error.restype = C.c_char_p
         L.nbody_ctx_stream.restype = C.c_void_p
         L.nbody_bvh_nnodes.restype = C.c_uint32
+        L.nbody_shard_range.restype = None
         _lib = L
     return _lib
 
@@ -119,6 +126,61 @@ def configure_all_pairs(split=0, targets_per_thread=0, source_path=None):
     _check(lib().nbody_all_pairs_configure(split, targets_per_thread))
     if source_path is not None:
         _check(lib().nbody_all_pairs_source_path(int(source_path)))
+
+
+def tuning(split=0, targets_per_thread=0, source_path=0):
+    """NBODY_TUNING(split, targets_per_thread, source_path) of include/nbody_hip.h; 0 = the library default."""
+    if not (split or targets_per_thread or source_path):
+        return 0
+    return (split & 15) | ((targets_per_thread & 3) << 4) | ((source_path & 3) << 6) | 0x100
+
+
+def describe_all_pairs(st):
+    """The K1 launch the library will make for this view (kernel template arguments, tile, chunks, pair math)."""
+    buf = C.create_string_buffer(256)
+    _check(lib().nbody_all_pairs_describe(C.byref(st), buf, C.c_size_t(256)))
+    return buf.value.decode()
+
+
+def shard_range(n, rank, world):
+    """nbody_shard_range: rank r of W owns bodies [n*r//W, n*(r+1)//W) — the partition the collective assumes."""
+    f, c = C.c_uint32(), C.c_uint32()
+    lib().nbody_shard_range(C.c_uint32(n), world, rank, C.byref(f), C.byref(c))
+    return f.value, f.value + c.value
+
+
+class Comm:
+    """nbody_comm: the RCCL communicator of the per-step all-gather of positions (one process per GPU form)."""
+
+    def __init__(self, world, rank, unique_id, device):
+        self.h = C.c_void_p()
+        assert len(unique_id) == COMM_ID_BYTES
+        _check(lib().nbody_comm_create(C.byref(self.h), world, rank, C.c_char_p(bytes(unique_id)), device))
+        self.world, self.rank = world, rank
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(COMM_ID_BYTES)
+        _check(lib().nbody_comm_get_unique_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rccl_version():
+        return int(lib().nbody_comm_rccl_version())
+
+    def allgather_positions(self, st, stream=None):
+        _check(lib().nbody_allgather_positions(self.h, C.byref(st), C.c_void_p(stream)))
+
+    def close(self):
+        if self.h:
+            lib().nbody_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HostSystem:
@@ -318,6 +380,14 @@ class DeviceSystem:
     def sync(self):
         _check(lib().nbody_stream_sync(C.c_void_p(self.stream)))
 
+    def configure_all_pairs(self, split=0, targets_per_thread=0, source_path=0):
+        """K1 launch shape of THIS context (nbody_ctx_configure_all_pairs); state() then carries it in `tuning`."""
+        _check(lib().nbody_ctx_configure_all_pairs(self.h, split, targets_per_thread, source_path))
+
+    def set_shard(self, first, count):
+        """nbody_ctx_set_shard: this context owns targets [first, first+count) (multi-GPU all-pairs)."""
+        _check(lib().nbody_ctx_set_shard(self.h, C.c_uint32(first), C.c_uint32(count)))
+
     # K1/K2/K3
     def all_pairs_force(self, first=0, count=None):
         st = self.state(first, count)
@@ -417,9 +487,14 @@ def executed_steps(steps, csv_detailed, warmup=10):
     return steps if csv_detailed else max(steps, warmup)
 
 
+OCTREE_CHECK_EVERY = 64
+
+
 def run(dev, algorithm, nsteps, theta=0.5):
-    """The step loop of run_all_pairs / run_bvh on the device."""
-    for _ in range(nsteps):
+    """The step loop of run_all_pairs / run_bvh / run_octree on the device.  Octree builds report trouble (bodies that
+    never separate, node pool, walk stack or step budget exhausted) through a sticky device-side flag: it is read every
+    OCTREE_CHECK_EVERY steps and after the last one, and raises — a flagged build drops mass, never integrate on."""
+    for k in range(nsteps):
         if algorithm == "all-pairs":
             dev.all_pairs_force()
         elif algorithm == "all-pairs-collapsed":
@@ -428,7 +503,11 @@ def run(dev, algorithm, nsteps, theta=0.5):
             dev.bvh_force(theta)
         elif algorithm == "octree":
             dev.octree_force(theta)
+            if (k + 1) % OCTREE_CHECK_EVERY == 0:
+                dev.octree.info(dev.stream)
         else:
             raise ValueError(algorithm)
         dev.accelerate_step()
+    if algorithm == "octree" and nsteps > 0:
+        dev.octree.info(dev.stream)
     dev.sync()

@@ -29,6 +29,7 @@
 // over count*D scalars, FP contraction off so it is bit-identical to the reference's x86 -O2 build.
 #include "common.hpp"
 
+#include <atomic>
 #include <mutex>
 #include <vector>
 
@@ -36,14 +37,23 @@ namespace nbody {
 
 constexpr int kBlock = 256;  // 4 waves
 constexpr int kWaves = kBlock / 64;
-constexpr int kTileJ = 512;  // sources per LDS tile (fixed: the rounding order depends on it)
 
 struct ap_config {
   int split = 0;  // 0 = auto
   int tpt   = 0;  // targets per thread, 0 = auto
   int path  = 0;  // source path: 0 = auto (scalar stream), 1 = LDS tiles, 2 = scalar stream
 };
-static ap_config g_ap_config;
+// process-wide default in NBODY_TUNING encoding (0 = all auto); a view with a non-zero `tuning` overrides it
+static std::atomic<uint32_t> g_ap_default{0};
+
+static ap_config ap_config_of(const nbody_state* s) {
+  const uint32_t t = s->tuning ? s->tuning : g_ap_default.load(std::memory_order_relaxed);
+  ap_config c;
+  c.split = int(t & 15u);
+  c.tpt   = int((t >> 4) & 3u);
+  c.path  = int((t >> 6) & 3u);
+  return c;
+}
 
 // ------------------------------------------------------------------------------------------------
 // K1
@@ -82,6 +92,7 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
   }
 
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
+  const pair_consts<T> pc;
 
   // register staging of one tile: LPT records per lane
   rec_t stage[LPT];
@@ -111,11 +122,13 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
     if (t + 1 < ntiles) stage_load(t + 1);  // in flight while this tile is consumed
 
     const rec_t* src = &tile[jpart * SUB];
-#pragma unroll 4
-    for (int jj = 0; jj < SUB; ++jj) {
-      rec_t s = src[jj];  // wave-uniform address: LDS broadcast
+    constexpr int U  = 64 / int(sizeof(rec_t));  // the scalar-stream form's batch: 2 records in f64, 4 in f32
+#pragma unroll 2
+    for (int jj = 0; jj < SUB; jj += U) {
+      rec_t s[U];
 #pragma unroll
-      for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], s);
+      for (int u = 0; u < U; ++u) s[u] = src[jj + u];  // wave-uniform address: LDS broadcast
+      pair_batch<T, D, R, U>(acc, xi, s, pc);
     }
   }
 
@@ -149,21 +162,6 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
   }
 }
 
-typedef uint32_t sgpr16 __attribute__((ext_vector_type(16)));
-// `tie` is a VGPR value the surrounding arithmetic reads (sload16) or produces (swait): the statements carry no
-// instruction for it, it only pins them in program order relative to that arithmetic (inline asm is otherwise free to
-// drift across pure FP code during instruction selection).
-template <typename V>
-__device__ __forceinline__ sgpr16 sload16(const void* p, V& tie) {  // p wave-uniform, 4-byte aligned
-  sgpr16 r;
-  asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=s"(r), "+v"(tie) : "s"(p));
-  return r;
-}
-template <typename V>
-__device__ __forceinline__ void swait(sgpr16& v, V& tie) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(tie));
-}
-
 // Scalar-stream form: pre-pass that packs (x, m) into aligned records, zero-mass padding up to a whole tile
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restrict__ m, const T* __restrict__ x,
@@ -183,7 +181,9 @@ constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the
 template <typename T, int D, int R, int JS>
 __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
                                                                                    const T* __restrict__ x, T* __restrict__ a, T c,
-                                                                                   uint32_t sz, uint32_t first, uint32_t count) {
+                                                                                   uint32_t sz, uint32_t first, uint32_t count,
+                                                                                   uint32_t tiles_per_chunk,
+                                                                                   T* __restrict__ chunk_sums) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kSgprWaves<JS> / JS;
   constexpr int TB  = TG * 64 * R;
@@ -206,13 +206,17 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
       acc[r][k] = T(0);
     }
   }
+  // source chunk of this block (grid.y): tiles [t0, t1) of the padded source set; one chunk = everything when grid.y == 1
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
-  const uint32_t nsteps = ntiles * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
+  const uint32_t t0     = blockIdx.y * tiles_per_chunk;
+  const uint32_t t1     = min(ntiles, t0 + tiles_per_chunk);
+  const pair_consts<T> pc;
+  const uint32_t nsteps = (t1 - t0) * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
   constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
   struct batch_t {
     rec_t r[U];
   };
-  auto batch = [&](uint32_t k) { return packed + (uint64_t(k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
+  auto batch = [&](uint32_t k) { return packed + (uint64_t(t0 + k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
   // Two SGPR buffers, each requested (s_load_dwordx16) one compute phase before it is consumed.  Written with inline
   // asm: hipcc folds a loop-carried load from read-only memory back into a load at the loop top and waits for it there.
   // SMEM returns out of order, so the only usable wait is lgkmcnt(0): wait for X, request Y, consume X.
@@ -222,19 +226,13 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
     B = sload16(batch(k + U), xi[0][0]);
     {
       const batch_t ba = __builtin_bit_cast(batch_t, A);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], ba.r[u]);
+      pair_batch<T, D, R, U>(acc, xi, ba.r, pc);
     }
     swait(B, acc[0][0]);
     A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
     {
       const batch_t bb = __builtin_bit_cast(batch_t, B);
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], bb.r[u]);
+      pair_batch<T, D, R, U>(acc, xi, bb.r, pc);
     }
   }
   swait(A, acc[0][0]);  // nothing in flight when the wave goes on
@@ -256,90 +254,206 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
     }
   }
   if (jpart == 0) {
+    // one chunk: the result; several: this chunk's sum, combined in chunk order by combine_chunks_kernel
+    T* out = chunk_sums ? chunk_sums + uint64_t(blockIdx.y) * count * D : a;
+    const T scale = chunk_sums ? T(1) : c;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (ti[r] < count) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) a[uint64_t(ti[r]) * D + k] = c * acc[r][k];
+        for (int k = 0; k < D; ++k) out[uint64_t(ti[r]) * D + k] = scale * acc[r][k];
       }
     }
   }
 }
 
-// Packed-source scratch, one buffer per stream that has called the scalar-stream form (grow-only).  A context
+// a = c * (((s_0 + s_1) + s_2) + ...) over the source chunks, in chunk order
+template <typename T>
+__global__ __launch_bounds__(kBlock) void combine_chunks_kernel(const T* __restrict__ chunk_sums, T* __restrict__ a, T c,
+                                                                uint64_t n, uint32_t nchunks) {
+  const uint64_t e = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (e >= n) return;
+  T sum = chunk_sums[e];
+  for (uint32_t y = 1; y < nchunks; ++y) sum += chunk_sums[uint64_t(y) * n + e];
+  a[e] = c * sum;
+}
+
+// Scratch (packed sources; per-chunk sums), one slot per (device, stream) that has called the scalar-stream form (grow-only).  A context
 // reserves its buffer when it is created (nbody_create), so that a step recorded with nbody_graph_begin never has to
-// allocate; other callers get theirs on the first call, which therefore must not be inside a capture.
+// allocate; other callers get theirs on the first call, which therefore must not be inside a capture.  A buffer that is
+// outgrown is retired, not freed: a recorded graph or a launch another host thread is about to make may still name it.
+// Retired buffers go when the slot is released (nbody_destroy) — at most log2(growth) of them, the largest last.
 namespace {
+struct scratch_buf {
+  void* ptr  = nullptr;
+  size_t cap = 0;
+};
 struct packed_slot {
+  int device;
   hipStream_t stream;
-  void* ptr;
-  size_t cap;
+  scratch_buf buf[3];  // 0: packed sources, 1: K1 per-chunk sums, 2: energies work area
+  std::vector<void*> retired;
 };
 std::mutex g_packed_mu;
 std::vector<packed_slot> g_packed_slots;
 }  // namespace
 
-int ap_scratch_get(hipStream_t st, size_t bytes, void** out) {
+int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out) {
+  const int dev = stream_device(st);
   std::lock_guard<std::mutex> lock(g_packed_mu);
   packed_slot* slot = nullptr;
   for (auto& sl : g_packed_slots)
-    if (sl.stream == st) slot = &sl;
-  if (slot && slot->cap >= bytes) {
-    *out = slot->ptr;
+    if (sl.stream == st && sl.device == dev) slot = &sl;
+  if (slot && slot->buf[which].cap >= bytes) {
+    *out = slot->buf[which].ptr;
     return NBODY_OK;
   }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (st != nullptr) (void)hipStreamIsCapturing(st, &cs);
   if (cs != hipStreamCaptureStatusNone) {
-    set_error("all-pairs: the packed-source buffer of this stream must exist before a step is recorded "
+    set_error("all-pairs: the scratch buffers of this stream must exist before a step is recorded "
               "(call nbody_all_pairs_force once outside nbody_graph_begin/end, or use a context from nbody_create)");
     return NBODY_ERR_STATE;
   }
   if (!slot) {
-    g_packed_slots.push_back({st, nullptr, 0});
+    g_packed_slots.push_back({dev, st, {}, {}});
     slot = &g_packed_slots.back();
   }
-  if (slot->ptr) NB_HIP(hipFree(slot->ptr));  // hipFree waits for the device: no launch still reads the old buffer
-  slot->ptr = nullptr;
-  slot->cap = 0;
-  NB_HIP(hipMalloc(&slot->ptr, bytes));
-  slot->cap = bytes;
-  *out      = slot->ptr;
+  void* fresh = nullptr;
+  NB_HIP(hipMalloc(&fresh, bytes));  // on the stream's device: the caller holds a device_guard
+  if (slot->buf[which].ptr) slot->retired.push_back(slot->buf[which].ptr);
+  slot->buf[which].ptr = fresh;
+  slot->buf[which].cap = bytes;
+  *out                 = fresh;
   return NBODY_OK;
 }
 
-int ap_scratch_reserve(hipStream_t st, int dtype, uint32_t n) {
-  void* p             = nullptr;
-  const size_t padded = (size_t(n) + kTileJ - 1) / kTileJ * kTileJ;
-  return ap_scratch_get(st, (dtype == NBODY_F32 ? 16u : 32u) * padded, &p);
-}
-
 void ap_scratch_release(hipStream_t st) {
+  const int dev = stream_device(st);
   std::lock_guard<std::mutex> lock(g_packed_mu);
   for (size_t i = 0; i < g_packed_slots.size(); ++i) {
-    if (g_packed_slots[i].stream == st) {
-      (void)hipFree(g_packed_slots[i].ptr);
+    if (g_packed_slots[i].stream == st && g_packed_slots[i].device == dev) {
+      for (auto& b : g_packed_slots[i].buf) (void)hipFree(b.ptr);
+      for (void* p : g_packed_slots[i].retired) (void)hipFree(p);
       g_packed_slots.erase(g_packed_slots.begin() + long(i));
       return;
     }
   }
 }
 
+// ---- launch plan -----------------------------------------------------------------------------------------------
+// What fixes the ROUNDING ORDER of a target's sum is derived from sz alone — never from first/count — so every shard
+// of a multi-GPU run sums exactly as the single-GPU run does:
+//   * split  (JS): the 512-record tile is cut into JS slices, one per wave of a target group; 8 slices (512-thread
+//     blocks, scalar-stream form only) once sz >= 65 536, else 4;
+//   * chunks (Y):  the tile sequence is cut into Y runs, one per grid.y, each run summed by its own block and the Y
+//     sums combined in run order by a second kernel.  Equal-sized blocks that start together finish together, so a
+//     launch costs ceil(blocks / resident slots) block times: 1563 blocks on 1024 slots (N = 10^5) ran at 31 % of peak
+//     against 39 % for N = 2^20.  Y makes the blocks short and many (>= 16 rounds for the whole system, >= 8 for a
+//     1/8 shard) whatever N is; co-resident blocks then also share one 128 KB..1 MB run of source records in L2.
+// What does NOT touch the order may depend on the window: targets per lane (R) and the LDS / scalar-stream choice.
+struct k1_plan {
+  bool scalar = false;
+  int r = 1, js = 4;
+  uint32_t chunks = 1, tiles_per_chunk = 0;
+};
+
+static int auto_split(uint32_t sz) { return sz >= 65536u ? 8 : 4; }
+
+void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk) {
+  const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
+  uint32_t y = 1;
+  // 2^22 / sz runs (4 at N = 2^20, 16 at 262 144, 64 -> capped below at 65 536), each at least 8 tiles (4096 sources) long
+  while (y < 64 && uint64_t(y) * 2 * sz <= (1ull << 22) && ntiles / (y * 2) >= 8) y *= 2;
+  uint32_t tpc = (ntiles + y - 1) / y;
+  if (tpc == 0) tpc = 1;
+  *tiles_per_chunk = tpc;
+  *chunks          = ntiles ? (ntiles + tpc - 1) / tpc : 1;
+}
+
+template <typename T>
+static int plan_all_pairs(const nbody_state* s, k1_plan* out) {
+  const ap_config cfg = ap_config_of(s);
+  k1_plan p;
+  p.js = cfg.split ? cfg.split : auto_split(s->sz);
+  p.r  = cfg.tpt;
+  // Source path (bitwise identical results, so the choice may depend on the shard size).  The scalar stream pays an SMEM
+  // round trip per 64-byte batch, which needs several waves per SIMD to hide: measured f64, split 4, lds / sgpr:
+  // 0.16 / 0.34 ms at N = 10^4, 0.78 / 0.98 ms at 3*10^4, 3.20 / 3.11 ms at 65 536, 8.62 / 8.32 ms at 10^5, 746 / 722 ms at 2^20.
+  const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * uint64_t(p.js);
+  p.scalar                = p.js == 8 || cfg.path == 2 || (cfg.path == 0 && waves_r1 >= 4096);
+  if (p.js == 8 && cfg.path == 1) {
+    set_error("all-pairs: the LDS-tile form has at most 4 source slices; sz = %u uses 8 (nbody_all_pairs_configure(4, ...) to force 4)",
+              s->sz);
+    return NBODY_ERR_ARG;
+  }
+  // source chunks: only where the split is the automatic one of large systems (so every explicit configuration keeps
+  // its single-chunk order) and only in the scalar-stream form
+  p.tiles_per_chunk = (s->sz + kTileJ - 1) / kTileJ;
+  if (p.scalar && cfg.split == 0 && p.js == 8) ap_auto_chunks(s->sz, &p.chunks, &p.tiles_per_chunk);
+  if (p.r == 0) {
+    // R = 2 halves the scalar-cache traffic per pair and the block count; it pays once the grid is many rounds deep.
+    const uint64_t blocks_r2 = (uint64_t(s->count) + 127) / 128 * p.chunks;
+    if (p.scalar) p.r = (sizeof(T) == 8 && blocks_r2 >= 4096) ? 2 : 1;
+    else p.r = blocks_r2 * uint64_t(p.js) >= 8192 ? 2 : 1;
+  }
+  *out = p;
+  return NBODY_OK;
+}
+
+int ap_scratch_reserve(hipStream_t st, int dtype, int dim, uint32_t n) {
+  void* p             = nullptr;
+  const size_t tsz    = dtype == NBODY_F32 ? 4 : 8;
+  const size_t padded = (size_t(n) + kTileJ - 1) / kTileJ * kTileJ;
+  if (int r = ap_scratch_get(st, 0, 4 * tsz * padded, &p)) return r;
+  uint32_t chunks = 1, tpc = 0;
+  if (auto_split(n) == 8) ap_auto_chunks(n, &chunks, &tpc);
+  if (chunks > 1) return ap_scratch_get(st, 1, tsz * size_t(n) * size_t(dim) * chunks, &p);
+  return NBODY_OK;
+}
+
+// packs (x, m) of all sz bodies into this stream's record buffer (stream-ordered); used by K1 and by the energies
+int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out) {
+  const uint32_t padded = (s->sz + kTileJ - 1) / kTileJ * kTileJ;
+  const size_t tsz      = s->dtype == NBODY_F32 ? 4 : 8;
+  void* scratch         = nullptr;
+  if (int r = ap_scratch_get(st, 0, 4 * tsz * size_t(padded), &scratch)) return r;
+  int rc = dispatch(s->dtype, s->dim, [&](auto tg) {
+    using T         = typename decltype(tg)::type;
+    constexpr int D = decltype(tg)::dim;
+    hipLaunchKernelGGL((pack_sources_kernel<T, D>), dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<src_rec<T, D>*>(scratch), s->sz, padded);
+    NB_HIP(hipGetLastError());
+    return int(NBODY_OK);
+  });
+  *packed_out = scratch;
+  return rc;
+}
+
 template <typename T, int D, int R, int JS>
-static int launch_all_pairs_sgpr(const nbody_state* s, hipStream_t st) {
+static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipStream_t st) {
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  const uint32_t padded = (s->sz + kTileJ - 1) / kTileJ * kTileJ;
-  void* scratch         = nullptr;
-  if (int r = ap_scratch_get(st, sizeof(src_rec<T, D>) * size_t(padded), &scratch)) return r;
+  T* sums = nullptr;
+  if (plan.chunks > 1) {  // before anything is queued: a failed reservation leaves the stream untouched
+    void* q = nullptr;
+    if (int r = ap_scratch_get(st, 1, sizeof(T) * size_t(s->count) * D * plan.chunks, &q)) return r;
+    sums = static_cast<T*>(q);
+  }
+  void* scratch = nullptr;
+  if (int r = ap_pack_sources(s, st, &scratch)) return r;
   auto* packed = static_cast<src_rec<T, D>*>(scratch);
-  hipLaunchKernelGGL((pack_sources_kernel<T, D>), dim3((padded + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), packed, s->sz, padded);
+  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
+                     packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                     plan.tiles_per_chunk, sums);
   NB_HIP(hipGetLastError());
-  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks), dim3(64 * kSgprWaves<JS>), 0, st, packed,
-                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count);
-  NB_HIP(hipGetLastError());
+  if (sums) {
+    const uint64_t n = uint64_t(s->count) * D;
+    hipLaunchKernelGGL((combine_chunks_kernel<T>), dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sums,
+                       static_cast<T*>(s->a), static_cast<T>(s->c), n, plan.chunks);
+    NB_HIP(hipGetLastError());
+  }
   return NBODY_OK;
 }
 
@@ -354,38 +468,13 @@ static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
   return NBODY_OK;
 }
 
-// Source split: chosen from sz ONLY (never from first/count) so that every shard of a multi-GPU run
-// sums in the same order as the single-GPU run.  8 slices (512-thread blocks, scalar-stream form only) once the system
-// is large enough for that form: twice the waves for the same work, which is what a 1/8 shard of N = 2^20 lacks
-// (93.1 vs 97.6 ms; whole system 720 vs 730 ms; N = 65 536: 2.92 vs 3.08 ms).  Small systems keep 4.
-static int auto_split(uint32_t sz) { return sz >= 65536u ? 8 : 4; }
-
 template <typename T, int D>
 static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
-  int js = g_ap_config.split ? g_ap_config.split : auto_split(s->sz);
-  int r  = g_ap_config.tpt;
-  // Source path (bitwise identical results, so the choice may depend on the shard size).  The scalar stream pays an SMEM
-  // round trip per 64-byte batch, which needs several waves per SIMD to hide: measured f64, split 4, lds / sgpr:
-  // 0.16 / 0.34 ms at N = 10^4, 0.78 / 0.98 ms at 3*10^4, 3.20 / 3.11 ms at 65 536, 8.62 / 8.32 ms at 10^5, 746 / 722 ms at 2^20.
-  const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * js;
-  const bool scalar       = js == 8 || g_ap_config.path == 2 || (g_ap_config.path == 0 && waves_r1 >= 4096);
-  if (js == 8 && g_ap_config.path == 1) {
-    set_error("all-pairs: the LDS-tile form has at most 4 source slices; sz = %u uses 8 (nbody_all_pairs_configure(4, ...) to force 4)",
-              s->sz);
-    return NBODY_ERR_ARG;
-  }
-  if (r == 0) {
-    // R = 2 halves the record traffic per pair; it pays when its blocks still spread evenly over the 256 CUs.
-    // Measured (scalar form, f64): N = 65 536 (512 blocks) 2.92 vs 2.95 ms, 10^5 (782 blocks) 9.40 vs 8.10 ms, 262 144
-    // (2048) 45.8 vs 46.6 ms, 2^20 720 vs 723 ms, its 1/8 shard (1024) 93.1 vs 96.0 ms; never in f32 (24.8 vs 23.0 ms at
-    // 262 144).  LDS form: >= 8 waves per SIMD.
-    const uint64_t blocks_r2 = (uint64_t(s->count) + 127) / 128;
-    if (scalar) r = (sizeof(T) == 8 && (blocks_r2 >= 2048 || (blocks_r2 >= 512 && blocks_r2 % 256 == 0))) ? 2 : 1;
-    else r = blocks_r2 * js >= 8192 ? 2 : 1;
-  }
+  k1_plan p;
+  if (int rc = plan_all_pairs<T>(s, &p)) return rc;
 #define NB_CASE(RR, JJ)                                                            \
-  if (r == RR && js == JJ)                                                         \
-  return scalar ? launch_all_pairs_sgpr<T, D, RR, JJ>(s, st) : launch_all_pairs<T, D, RR, JJ>(s, st)
+  if (p.r == RR && p.js == JJ)                                                     \
+  return p.scalar ? launch_all_pairs_sgpr<T, D, RR, JJ>(s, p, st) : launch_all_pairs<T, D, RR, JJ>(s, st)
   NB_CASE(1, 1);
   NB_CASE(1, 2);
   NB_CASE(1, 4);
@@ -393,12 +482,26 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   NB_CASE(2, 2);
   NB_CASE(2, 4);
 #undef NB_CASE
-  if (scalar && js == 8) {
-    if (r == 1) return launch_all_pairs_sgpr<T, D, 1, 8>(s, st);
-    if (r == 2) return launch_all_pairs_sgpr<T, D, 2, 8>(s, st);
+  if (p.scalar && p.js == 8) {
+    if (p.r == 1) return launch_all_pairs_sgpr<T, D, 1, 8>(s, p, st);
+    if (p.r == 2) return launch_all_pairs_sgpr<T, D, 2, 8>(s, p, st);
   }
-  set_error("all-pairs: unsupported config split=%d targets_per_thread=%d", js, r);
+  set_error("all-pairs: unsupported config split=%d targets_per_thread=%d", p.js, p.r);
   return NBODY_ERR_ARG;
+}
+
+template <typename T, int D>
+static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
+  k1_plan p;
+  if (int rc = plan_all_pairs<T>(s, &p)) return rc;
+  const char* t = sizeof(T) == 8 ? "double" : "float";
+  if (p.scalar)
+    snprintf(out, len, "all_pairs_force_sgpr_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=%u pair=%s", t, D, p.r, p.js, kTileJ, p.chunks,
+             sizeof(T) == 8 ? "far3/near2" : "rsq+rcp");
+  else
+    snprintf(out, len, "all_pairs_force_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=1 pair=%s", t, D, p.r, p.js, kTileJ,
+             sizeof(T) == 8 ? "far3/near2" : "rsq+rcp");
+  return NBODY_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -603,22 +706,33 @@ static int accelerate_dispatch(const nbody_state* s, hipStream_t st) {
 using namespace nbody;
 
 extern "C" int nbody_all_pairs_configure(int split, int targets_per_thread) {
-  NB_ARG(split == 0 || split == 1 || split == 2 || split == 4 || split == 8, "split must be 0, 1, 2, 4 or 8 (got %d)", split);
-  NB_ARG(targets_per_thread >= 0 && targets_per_thread <= 2, "targets_per_thread must be 0, 1 or 2 (got %d)",
-         targets_per_thread);
-  g_ap_config.split = split;
-  g_ap_config.tpt   = targets_per_thread;
+  const uint32_t cur = g_ap_default.load(std::memory_order_relaxed);
+  if (int r = check_tuning(split, targets_per_thread, int((cur >> 6) & 3u))) return r;
+  uint32_t want = (cur & (3u << 6)) | uint32_t(split & 15) | (uint32_t(targets_per_thread & 3) << 4);
+  g_ap_default.store(want, std::memory_order_relaxed);
   return NBODY_OK;
 }
 
 extern "C" int nbody_all_pairs_source_path(int mode) {
-  NB_ARG(mode >= 0 && mode <= 2, "source path must be 0 (auto), 1 (LDS tiles) or 2 (scalar stream), got %d", mode);
-  g_ap_config.path = mode;
+  if (int r = check_tuning(0, 0, mode)) return r;
+  uint32_t cur = g_ap_default.load(std::memory_order_relaxed);
+  while (!g_ap_default.compare_exchange_weak(cur, (cur & ~(3u << 6)) | (uint32_t(mode) << 6), std::memory_order_relaxed)) {
+  }
   return NBODY_OK;
+}
+
+extern "C" int nbody_all_pairs_describe(const nbody_state* s, char* out, size_t len) {
+  NB_ARG(out != nullptr && len > 0, "out is NULL");
+  if (int r = check_state(s)) return r;
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using TG = decltype(tg);
+    return all_pairs_describe<typename TG::type, TG::dim>(s, out, len);
+  });
 }
 
 extern "C" int nbody_all_pairs_force(const nbody_state* s, void* stream) {
   if (int r = check_state(s)) return r;
+  device_guard guard(stream_device(as_stream(stream)));
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return all_pairs_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
@@ -627,6 +741,7 @@ extern "C" int nbody_all_pairs_force(const nbody_state* s, void* stream) {
 
 extern "C" int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream) {
   if (int r = check_state(s)) return r;
+  device_guard guard(stream_device(as_stream(stream)));
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return collapsed_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
@@ -635,6 +750,7 @@ extern "C" int nbody_all_pairs_collapsed_force(const nbody_state* s, void* strea
 
 extern "C" int nbody_accelerate_step(const nbody_state* s, void* stream) {
   if (int r = check_state(s)) return r;
+  device_guard guard(stream_device(as_stream(stream)));
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return accelerate_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));

@@ -42,7 +42,7 @@ struct alignas(sizeof(T) * 8) tree_rec {
 }  // namespace nbody
 
 struct nbody_bvh {
-  int dtype = 0, dim = 0;
+  int dtype = 0, dim = 0, device = 0;  // device: the one current at nbody_bvh_create; every call runs there
   uint32_t n = 0, nlevels = 0, nnodes = 0;
   size_t tsz = 0, rec_bytes = 0;
   uint32_t sort_blocks = 0, bbox_blocks = 0;
@@ -712,6 +712,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
   NB_ARG(n >= 2 && n <= (1u << 30), "bvh needs 2 <= n <= 2^30 (got %u)", n);
   auto* t  = new nbody_bvh;
+  t->device = current_device();
   t->dtype = dtype;
   t->dim   = dim;
   t->n     = n;
@@ -758,6 +759,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
 
 extern "C" void nbody_bvh_destroy(nbody_bvh* t) {
   if (!t) return;
+  device_guard guard(t->device);
   (void)hipFree(t->bbox);
   (void)hipFree(t->partials);
   (void)hipFree(t->keys[0]);
@@ -776,6 +778,7 @@ extern "C" uint32_t nbody_bvh_nnodes(const nbody_bvh* t) { return t ? t->nnodes 
 
 extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
+  device_guard guard(t->device);
   if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 4 * size_t(t->n)));
   t->counters_on = on != 0;
   return NBODY_OK;
@@ -790,6 +793,7 @@ extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
 
 extern "C" int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* stream) {
   if (int r = check_tree(t, s, false)) return r;
+  device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return bbox_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
@@ -800,6 +804,7 @@ extern "C" int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* 
 
 extern "C" int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xmax_out, void* stream) {
   NB_ARG(t != nullptr && xmin_out && xmax_out, "NULL argument");
+  device_guard guard(t->device);
   if (!t->have_bbox) {
     set_error("nbody_bvh_get_bounding_box before nbody_bvh_bounding_box");
     return NBODY_ERR_STATE;
@@ -814,6 +819,7 @@ extern "C" int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xm
 
 extern "C" int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* stream) {
   if (int r = check_tree(t, s, true)) return r;
+  device_guard guard(t->device);
   if (!t->have_bbox) {
     set_error("nbody_bvh_hilbert_sort before nbody_bvh_bounding_box");
     return NBODY_ERR_STATE;
@@ -828,6 +834,7 @@ extern "C" int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* 
 
 extern "C" int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* stream) {
   if (int r = check_tree(t, s, false)) return r;
+  device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return build_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
@@ -838,6 +845,7 @@ extern "C" int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* st
 
 extern "C" int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, double theta, void* stream) {
   if (int r = check_tree(t, s, false)) return r;
+  device_guard guard(t->device);
   if (!t->built) {
     set_error("nbody_bvh_compute_force before nbody_bvh_build_tree");
     return NBODY_ERR_STATE;
@@ -850,6 +858,7 @@ extern "C" int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, doubl
 
 extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream) {
   NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
+  device_guard guard(t->device);
   const size_t D = size_t(t->dim);
   hipStream_t st = as_stream(stream);
   auto copy_out = [&](const void* dev, size_t need) -> int {

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 
 #include "../../include/nbody_hip.h"
 
@@ -29,6 +30,34 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line);
       return NBODY_ERR_ARG;              \
     }                                    \
   } while (0)
+
+// ---- devices --------------------------------------------------------------------------------------
+// One host thread may drive several GPUs (the CLI's --gpus N, ncclCommInitAll): every entry point runs on the device its
+// handle or stream belongs to and puts the caller's current device back when it returns.
+struct device_guard {
+  int prev     = -1;
+  bool changed = false;
+  explicit device_guard(int dev) {
+    if (dev >= 0 && hipGetDevice(&prev) == hipSuccess && prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+  }
+  ~device_guard() {
+    if (changed) (void)hipSetDevice(prev);
+  }
+  device_guard(const device_guard&)            = delete;
+  device_guard& operator=(const device_guard&) = delete;
+};
+
+inline int current_device() {
+  int d = -1;
+  return hipGetDevice(&d) == hipSuccess ? d : -1;
+}
+
+// device a stream was created on; the NULL stream belongs to whatever device is current
+inline int stream_device(hipStream_t st) {
+  if (st == nullptr) return current_device();
+  hipDevice_t d = -1;
+  return hipStreamGetDevice(st, &d) == hipSuccess ? int(d) : current_device();
+}
 
 inline int check_state(const nbody_state* s) {
   NB_ARG(s != nullptr, "nbody_state is NULL");
@@ -74,13 +103,11 @@ inline int dispatch(int dtype, int dim, F&& f) {
 template <typename T>
 struct pair_math;
 
-// NBODY_PAIR_POLISH: order of the polish applied to the two 2^-24 FP64 seeds.
+// NBODY_PAIR_POLISH: order of the polish applied to the two 2^-24 FP64 seeds of weight() — the form used by the tree
+// walks (K9, octree) and, in K1, only for pairs closer than 2^-8 (see weight_far below).
 //   2 (default): Newton steps  s = h + h*e/2,  w = zm + zm*e2        17 full-rate ops + 2 transcendentals per pair.
 //      Per-term error bound: +3/8*e^2 (e <= 2^-23.2) - e2^2 (e2 <= 2^-24.4)  =>  within [-2e-15, +4.1e-15] relative.
-//      Measured on accelerations against the oracle in the SAME summation order: max 1.9e-15, mean signed 4e-17 (no
-//      bias) — the same size as the order-of-summation differences (2-3e-15) and 3 decades under the 1e-12 parity
-//      tolerance.  758.6 ms per force pass at N=2^20 (36.9 % of FP64 peak).
-//   3: third-order steps (+2 FMA): <= 2 ulp per term (max 3e-16 on accelerations), 814 ms (34.4 %).
+//   3: third-order steps (+2 FMA): <= 2 ulp per term.
 #ifndef NBODY_PAIR_POLISH
   #define NBODY_PAIR_POLISH 2
 #endif
@@ -109,6 +136,31 @@ struct pair_math<double> {
 #else
     return __builtin_fma(zm, e2, zm);         // mj/d3 * (1 - e2^2)
 #endif
+  }
+
+  // The same quantity without the reciprocal, for r2 >= 2^-16 (K1's fast path).  With u = r2^(-3/2):
+  //     mj / (r2^(3/2) + eps) = mj * u / (1 + eps*u) = mj * u * (1 - eps*u + (eps*u)^2 - ...)
+  // and eps*u <= 2^-52 * 2^24 = 2^-28 there, so dropping (eps*u)^2 <= 2^-56 is below half an ulp.  u comes from the
+  // 2^-24 v_rsq_f64 seed y by one THIRD-order step on the cube:  y^3 * (1 - e)^(-3/2) = y^3 * (1 + 3/2 e + 15/8 e^2 + O(e^3)),
+  // e = 1 - r2*y^2 <= 2^-23 (truncation 35/16 e^3 < 3e-21).  Both corrections share one FMA:
+  //     w = (mj*y^3) * (1 + g),  g = e*(3/2 + 15/8 e) - eps*y^3          (the cross term of the two is < 2^-50 * 2^-28)
+  // 8 full-rate ops + 1 transcendental = 48 issue cycles per wave-pair instead of 12 + 2 = 80 for weight(), and only
+  // rounding error is left: a = fl(y*y) perturbs e by <= 2^-53 (x 3/2 in w), then y^3, mj*y^3 and the final FMA round once
+  // each: <= 2.5 ulp per term, no bias (measured in tests/test_gpu_all_pairs.py::test_pair_term_accuracy).
+  static constexpr uint32_t near_hi = 0x3EF00000u;  // high word of 2^-16: r2 below this takes weight()
+  // k15 = 1.5 in a VGPR pair and k1875 = 1.875 in an SGPR pair, held by the caller (pair_consts): neither is an inline
+  // constant, and left to itself hipcc feeds a VOP2 v_fmac with the literal and re-creates 1.5 in its accumulator
+  // operand with a v_mov per pair.
+  __device__ static __forceinline__ double weight_far(double r2, double mj, double k15, double k1875) {
+    double y  = __builtin_amdgcn_rsq(r2);
+    double a  = y * y;
+    double e  = __builtin_fma(-r2, a, 1.0);
+    double y3 = a * y;
+    double p  = __builtin_fma(e, k1875, k15);
+    double ey = DBL_EPSILON * y3;
+    double g  = __builtin_fma(p, e, -ey);
+    double my = mj * y3;
+    return __builtin_fma(my, g, my);
   }
 };
 
@@ -165,10 +217,106 @@ __device__ __forceinline__ void pair_accumulate_if(bool take, T (&acc)[D], const
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
 }
 
+// Loop-invariant operands of pair_batch that must stay in registers (made opaque to the optimiser once, outside the loop).
+template <typename T>
+struct pair_consts {
+  __device__ __forceinline__ pair_consts() {}
+};
+template <>
+struct pair_consts<double> {
+  double k15, k1875;
+  __device__ __forceinline__ pair_consts() : k15(1.5), k1875(1.875) {
+    asm volatile("" : "+v"(k15));
+    asm volatile("" : "+s"(k1875));
+  }
+};
+
+// K1's unit of work: U source records against the R targets of a lane.  acc[r] += w * (x_j - x_i) in source order.
+// f64: every pair takes weight_far() unless some lane of the wave holds a pair closer than 2^-8 (the self pair, a
+// coincident or a very close body: r2 < 2^-16, found with one v_min3_u32 per two pairs on the high words and ONE
+// wave-uniform branch per batch).  Then the wave evaluates weight() too and each lane keeps, pair by pair, the value
+// its own r2 asks for — so a pair's term depends on that pair alone, never on which other targets share the wave:
+// results stay bitwise independent of the shard window.  f32: v_rsq_f32/v_rcp_f32 are 1-ulp instructions, weight() as is.
+template <typename T, int D, int R, int U>
+__device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], const src_rec<T, D> (&s)[U],
+                                           const pair_consts<T>& pc) {
+  if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], s[u]);
+  } else {
+    T d[U][R][D], r2[U][R], w[U][R];
+    uint32_t lowest = 0xffffffffu;
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) d[u][r][k] = s[u].p[k] - xi[r][k];
+        T q = pair_math<T>::tiny;
+#pragma unroll
+        for (int k = 0; k < D; ++k) q = __builtin_elementwise_fma(d[u][r][k], d[u][r][k], q);
+        r2[u][r] = q;
+        const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, q) >> 32);
+        lowest            = hi < lowest ? hi : lowest;
+      }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::weight_far(r2[u][r], s[u].m, pc.k15, pc.k1875);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::near_hi) != 0ull, 0)) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
+          const T wn        = pair_math<T>::weight(r2[u][r], s[u].m);
+          w[u][r]           = hi < pair_math<T>::near_hi ? wn : w[u][r];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[r][k] = __builtin_elementwise_fma(w[u][r], d[u][r][k], acc[r][k]);
+  }
+}
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// all_pairs.hip: per-stream packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
-int ap_scratch_reserve(hipStream_t st, int dtype, uint32_t n);
+// ---- scalar-stream helpers (K1's default form, the energies) ------------------------------------------------
+constexpr int kTileJ = 512;  // source records per tile (fixed: the rounding order of K1 depends on it)
+
+typedef uint32_t sgpr16 __attribute__((ext_vector_type(16)));
+// `tie` is a VGPR value the surrounding arithmetic reads (sload16) or produces (swait): the statements carry no
+// instruction for it, it only pins them in program order relative to that arithmetic (inline asm is otherwise free to
+// drift across pure FP code during instruction selection).
+template <typename V>
+__device__ __forceinline__ sgpr16 sload16(const void* p, V& tie) {  // p wave-uniform, 4-byte aligned
+  sgpr16 r;
+  asm volatile("s_load_dwordx16 %0, %2, 0x0" : "=s"(r), "+v"(tie) : "s"(p));
+  return r;
+}
+template <typename V>
+__device__ __forceinline__ void swait(sgpr16& v, V& tie) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v), "+v"(tie));
+}
+
+// K1 launch shape: validation shared by the process-wide default and the per-context setting
+inline int check_tuning(int split, int tpt, int path) {
+  NB_ARG(split == 0 || split == 1 || split == 2 || split == 4 || split == 8, "split must be 0, 1, 2, 4 or 8 (got %d)", split);
+  NB_ARG(tpt >= 0 && tpt <= 2, "targets_per_thread must be 0, 1 or 2 (got %d)", tpt);
+  NB_ARG(path >= 0 && path <= 2, "source path must be 0 (auto), 1 (LDS tiles) or 2 (scalar stream), got %d", path);
+  return NBODY_OK;
+}
+
+// all_pairs.hip: per-(device, stream) packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
+int ap_scratch_reserve(hipStream_t st, int dtype, int dim, uint32_t n);
 void ap_scratch_release(hipStream_t st);
+int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 chunk sums, 2 energies
+int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);
+void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk);
 
 }  // namespace nbody

@@ -34,6 +34,8 @@ struct nbody_ctx {
   void *m = nullptr, *x = nullptr, *v = nullptr, *a = nullptr, *ao = nullptr;
   double dt = 0, c = 0;
   hipStream_t stream = nullptr;
+  uint32_t first = 0, count = 0;  // owned targets (nbody_ctx_set_shard); whole system by default
+  uint32_t tuning = 0;            // K1 launch shape of this context (nbody_ctx_configure_all_pairs)
 };
 
 extern "C" int nbody_abi_version(void) { return NBODY_HIP_ABI_VERSION; }
@@ -63,11 +65,12 @@ extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int
   int ndev = 0;
   NB_HIP(hipGetDeviceCount(&ndev));
   NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
-  NB_HIP(hipSetDevice(device));
+  device_guard guard(device);
   auto* c   = new nbody_ctx;
   c->dtype  = dtype;
   c->dim    = dim;
   c->n      = n;
+  c->count  = n;
   c->device = device;
   c->tsz    = dtype == NBODY_F32 ? 4 : 8;
   const size_t vb = c->tsz * size_t(n) * size_t(dim);
@@ -82,7 +85,7 @@ extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int
     nbody_destroy(c);
     return r;
   }
-  if (int r = ap_scratch_reserve(c->stream, dtype, n)) {  // so that a recorded step never allocates
+  if (int r = ap_scratch_reserve(c->stream, dtype, dim, n)) {  // so that a recorded step never allocates
     nbody_destroy(c);
     return r;
   }
@@ -92,6 +95,7 @@ extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int
 
 extern "C" void nbody_destroy(nbody_ctx* c) {
   if (!c) return;
+  device_guard guard(c->device);
   (void)hipFree(c->m);
   (void)hipFree(c->x);
   (void)hipFree(c->v);
@@ -105,6 +109,7 @@ extern "C" void nbody_destroy(nbody_ctx* c) {
 extern "C" int nbody_upload(nbody_ctx* c, const void* m, const void* x, const void* v, const void* a, const void* ao, double dt,
                             double cc) {
   NB_ARG(c && m && x && v && a && ao, "NULL argument");
+  device_guard guard(c->device);
   const size_t vb = c->tsz * size_t(c->n) * size_t(c->dim);
   NB_HIP(hipMemcpyAsync(c->m, m, c->tsz * size_t(c->n), hipMemcpyHostToDevice, c->stream));
   NB_HIP(hipMemcpyAsync(c->x, x, vb, hipMemcpyHostToDevice, c->stream));
@@ -119,36 +124,60 @@ extern "C" int nbody_upload(nbody_ctx* c, const void* m, const void* x, const vo
 
 extern "C" int nbody_download(nbody_ctx* c, void* m, void* x, void* v, void* a, void* ao) {
   NB_ARG(c != nullptr, "ctx is NULL");
-  const size_t vb = c->tsz * size_t(c->n) * size_t(c->dim);
+  device_guard guard(c->device);
+  // a sharded context returns its own rows only, at their place in the caller's full-size arrays
+  const size_t row = c->tsz * size_t(c->dim);
+  const size_t off = row * size_t(c->first), vb = row * size_t(c->count);
+  auto rows = [&](void* host, const void* dev) {
+    return hipMemcpyAsync(static_cast<char*>(host) + off, static_cast<const char*>(dev) + off, vb, hipMemcpyDeviceToHost, c->stream);
+  };
   if (m) NB_HIP(hipMemcpyAsync(m, c->m, c->tsz * size_t(c->n), hipMemcpyDeviceToHost, c->stream));
-  if (x) NB_HIP(hipMemcpyAsync(x, c->x, vb, hipMemcpyDeviceToHost, c->stream));
-  if (v) NB_HIP(hipMemcpyAsync(v, c->v, vb, hipMemcpyDeviceToHost, c->stream));
-  if (a) NB_HIP(hipMemcpyAsync(a, c->a, vb, hipMemcpyDeviceToHost, c->stream));
-  if (ao) NB_HIP(hipMemcpyAsync(ao, c->ao, vb, hipMemcpyDeviceToHost, c->stream));
+  if (x) NB_HIP(rows(x, c->x));
+  if (v) NB_HIP(rows(v, c->v));
+  if (a) NB_HIP(rows(a, c->a));
+  if (ao) NB_HIP(rows(ao, c->ao));
   NB_HIP(hipStreamSynchronize(c->stream));
   return NBODY_OK;
 }
 
 extern "C" int nbody_ctx_state(nbody_ctx* c, nbody_state* out) {
   NB_ARG(c && out, "NULL argument");
-  out->m     = c->m;
-  out->x     = c->x;
-  out->v     = c->v;
-  out->a     = c->a;
-  out->ao    = c->ao;
-  out->dt    = c->dt;
-  out->c     = c->c;
-  out->sz    = c->n;
-  out->first = 0;
-  out->count = c->n;
-  out->dtype = c->dtype;
-  out->dim   = c->dim;
+  const size_t off = c->tsz * size_t(c->dim) * size_t(c->first);
+  out->m      = c->m;
+  out->x      = c->x;
+  out->v      = static_cast<char*>(c->v) + off;  // record k of v/a/ao = body first + k
+  out->a      = static_cast<char*>(c->a) + off;
+  out->ao     = static_cast<char*>(c->ao) + off;
+  out->dt     = c->dt;
+  out->c      = c->c;
+  out->sz     = c->n;
+  out->first  = c->first;
+  out->count  = c->count;
+  out->dtype  = c->dtype;
+  out->dim    = c->dim;
+  out->tuning = c->tuning;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_ctx_set_shard(nbody_ctx* c, uint32_t first, uint32_t count) {
+  NB_ARG(c != nullptr, "ctx is NULL");
+  NB_ARG(uint64_t(first) + uint64_t(count) <= uint64_t(c->n), "shard [%u, %u+%u) exceeds n=%u", first, first, count, c->n);
+  c->first = first;
+  c->count = count;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_ctx_configure_all_pairs(nbody_ctx* c, int split, int targets_per_thread, int source_path) {
+  NB_ARG(c != nullptr, "ctx is NULL");
+  if (int r = check_tuning(split, targets_per_thread, source_path)) return r;
+  c->tuning = (split || targets_per_thread || source_path) ? NBODY_TUNING(split, targets_per_thread, source_path) : 0u;
   return NBODY_OK;
 }
 
 extern "C" void* nbody_ctx_stream(nbody_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }
 
 extern "C" int nbody_stream_sync(void* stream) {
+  device_guard guard(stream_device(as_stream(stream)));
   NB_HIP(hipStreamSynchronize(as_stream(stream)));
   return NBODY_OK;
 }
@@ -161,6 +190,7 @@ struct nbody_graph {
 
 extern "C" int nbody_graph_begin(void* stream) {
   NB_ARG(stream != nullptr, "graph capture needs an explicit (non-default) stream");
+  device_guard guard(stream_device(as_stream(stream)));
   NB_HIP(hipStreamBeginCapture(as_stream(stream), hipStreamCaptureModeThreadLocal));
   return NBODY_OK;
 }
@@ -168,6 +198,7 @@ extern "C" int nbody_graph_begin(void* stream) {
 extern "C" int nbody_graph_end(void* stream, nbody_graph** out) {
   NB_ARG(out != nullptr, "out is NULL");
   *out = nullptr;
+  device_guard guard(stream_device(as_stream(stream)));
   hipGraph_t graph = nullptr;
   NB_HIP(hipStreamEndCapture(as_stream(stream), &graph));
   hipGraphExec_t exec = nullptr;
@@ -185,6 +216,7 @@ extern "C" int nbody_graph_end(void* stream, nbody_graph** out) {
 
 extern "C" int nbody_graph_launch(nbody_graph* g, void* stream) {
   NB_ARG(g != nullptr && g->exec != nullptr, "graph is NULL");
+  device_guard guard(stream_device(as_stream(stream)));
   NB_HIP(hipGraphLaunch(g->exec, as_stream(stream)));
   return NBODY_OK;
 }

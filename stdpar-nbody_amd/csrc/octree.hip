@@ -32,7 +32,7 @@ namespace nbody {
 constexpr int kOB            = 256;
 constexpr uint32_t kOtEmpty  = 0xffffffffu;  // src/octree.h:37
 constexpr uint32_t kOtBody   = 0xfffffffeu;  // src/octree.h:38
-constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u;
+constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u, kFlagWalk = 8u;
 constexpr int kOtDeepLevels = 128;  // total depth the deep build follows before it calls the bodies coincident
 constexpr int kOtDeepFrames = 192;  // its DFS stack (one chain of close bodies needs ~2 per level)
 
@@ -799,8 +799,11 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
     if (!take) stack[g][sp + uint32_t(__builtin_popcount(open_mask >> (cc + 1u)))] = nd.fc;  // reverse child order
     sp += uint32_t(__builtin_popcount(open_mask));
     if (sp == 0u) break;
+    __builtin_amdgcn_wave_barrier();  // one lane pushed, all lanes of the group pop: keep the LDS write before the read
     cur = stack[g][--sp];
+    __builtin_amdgcn_wave_barrier();  // ... and this read before the next round's push into the same slot
   }
+  if (more && guard == 0xffffffffu && cc == 0) atomicOr(flags, kFlagWalk);  // step budget spent: the tree is damaged
   // combine the 2^D partial sums of a body (fixed order)
 #pragma unroll
   for (uint32_t off = NCH / 2; off > 0; off >>= 1) {
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
 
 // ---- host side / C ABI -----------------------------------------------------------------------------------------------
 struct nbody_octree {
-  int dtype = 0, dim = 0;
+  int dtype = 0, dim = 0, device = 0;  // device: the one current at nbody_octree_create; every call runs there
   uint32_t n = 0, capacity = 0, max_cells = 0, bounds_blocks = 0;
   size_t tsz = 0;
   void* root       = nullptr;  // T[D+1]: root_x (D), root_side_length
@@ -953,6 +956,7 @@ extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint3
   NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
   NB_ARG(n >= 1 && n <= (1u << 28), "octree needs 1 <= n <= 2^28 (got %u)", n);
   auto* t  = new nbody_octree;
+  t->device = current_device();
   t->dtype = dtype;
   t->dim   = dim;
   t->n     = n;
@@ -995,6 +999,7 @@ extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint3
 
 extern "C" void nbody_octree_destroy(nbody_octree* t) {
   if (!t) return;
+  device_guard guard(t->device);
   (void)hipFree(t->root);
   (void)hipFree(t->partials);
   (void)hipFree(t->keys[0]);
@@ -1020,6 +1025,7 @@ extern "C" int nbody_octree_clear(nbody_octree* t, void* stream) {
 
 extern "C" int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s, void* stream) {
   if (int r = ot_check(t, s)) return r;
+  device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return ot_bounds_run<typename TG::type, TG::dim>(t, s, as_stream(stream));
@@ -1030,6 +1036,7 @@ extern "C" int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s
 
 extern "C" int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* stream) {
   if (int r = ot_check(t, s)) return r;
+  device_guard guard(t->device);
   if (!t->have_bounds) {
     set_error("nbody_octree_insert before nbody_octree_compute_bounds");
     return NBODY_ERR_STATE;
@@ -1044,6 +1051,7 @@ extern "C" int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* 
 
 extern "C" int nbody_octree_compute_tree(nbody_octree* t, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+  device_guard guard(t->device);
   if (!t->inserted) {
     set_error("nbody_octree_compute_tree before nbody_octree_insert");
     return NBODY_ERR_STATE;
@@ -1058,6 +1066,7 @@ extern "C" int nbody_octree_compute_tree(nbody_octree* t, void* stream) {
 
 extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream) {
   if (int r = ot_check(t, s)) return r;
+  device_guard guard(t->device);
   if (!t->have_tree) {
     set_error("nbody_octree_compute_force before nbody_octree_compute_tree");
     return NBODY_ERR_STATE;
@@ -1070,6 +1079,7 @@ extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s,
 
 extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+  device_guard guard(t->device);
   if (on && !t->counters) NB_HIP(hipMalloc(reinterpret_cast<void**>(&t->counters), sizeof(uint32_t) * 2 * size_t(t->n)));
   t->counters_on = on != 0;
   return NBODY_OK;
@@ -1077,6 +1087,7 @@ extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {
 
 extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+  device_guard guard(t->device);
   if (!t->inserted) {
     set_error("nbody_octree_info before nbody_octree_insert");
     return NBODY_ERR_STATE;
@@ -1103,6 +1114,10 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
     set_error("octree walk: more pending nodes than the per-body stack holds (a tree far deeper than %d levels)", maxl);
     return NBODY_ERR_STATE;
   }
+  if (flags & kFlagWalk) {
+    set_error("octree walk: a body was still walking after %u steps (more than the tree has nodes: the tree is damaged)", t->capacity);
+    return NBODY_ERR_STATE;
+  }
   uint64_t cells = 0;
   for (int l = 0; l <= maxl + 1; ++l) cells += lv[l];  // breadth-first levels, then the groups of the deep build
   if (tree_size) *tree_size = uint32_t(1 + cells * (1u << t->dim));  // next_free_child_group (src/octree.h:152)
@@ -1113,6 +1128,7 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
 extern "C" int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream) {
   NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
   NB_ARG(t->counters != nullptr, "counters were never enabled");
+  device_guard guard(t->device);
   NB_ARG(bytes == sizeof(uint32_t) * 2 * size_t(t->n), "expected %zu bytes", sizeof(uint32_t) * 2 * size_t(t->n));
   NB_HIP(hipMemcpyAsync(host_out, t->counters, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
   NB_HIP(hipStreamSynchronize(as_stream(stream)));

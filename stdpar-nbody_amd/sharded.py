@@ -1,7 +1,10 @@
 """Body sharding for multi-GPU all-pairs: one process per GPU, targets split contiguously by rank, every
 rank keeps all N positions/masses, and ONE exchange per step — an all-gather of the updated position
-shards (RCCL over xGMI through torch.distributed; north_star / SURVEY §8e).  Nothing else moves:
-v, a, ao stay local; masses are constant and replicated at start-up.
+shards (north_star / SURVEY §8e).  Nothing else moves: v, a, ao stay local; masses are constant and replicated
+at start-up.  On GPUs the exchange is the library's own collective, nbody_allgather_positions (RCCL over xGMI
+behind the C ABI, in place on the x array, include/nbody_hip.h); the launcher only hands the RCCL unique id to the
+ranks.  The torch.distributed form of the same exchange (one all_gather over padded shards) remains for the
+CPU/gloo tests of the partition logic and as `exchange="torch"`.
 
 The reference has no counterpart (single process, single device).  The octree shards the same way (ShardedOctree:
 every rank rebuilds the whole tree from the gathered positions, walks it for its own bodies only).  bvh and
@@ -53,7 +56,7 @@ class HipOps:
 class ShardedAllPairs:
     """run_all_pairs' step (force, then accelerate_step; src/all_pairs.h:86-91) over a shard of targets."""
 
-    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None, force_exchange=False):
+    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None, force_exchange=False, comm=None):
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -79,7 +82,12 @@ class ShardedAllPairs:
         self.dt, self.c = float(hs.dt), float(hs.c)
         self.equal = hs.n % world == 0
         self.exchange = world > 1 or force_exchange  # force_exchange: run the collective even with one rank (smoke test)
-        self.send = torch.empty_like(self.x[self.first:end]) if self.exchange and self.equal else None
+        self.comm = comm                             # nbody_comm (C ABI): the exchange of the GPU path
+        self.shards = [shard_range(hs.n, r, world) for r in range(world)]
+        self.maxc = max(e - f for f, e in self.shards)
+        if self.exchange and comm is None:           # torch.distributed form: one all_gather over padded shards
+            self.send = torch.zeros((self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
+            self.recv = torch.empty((world * self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
 
     def state(self, whole=False):
         """The shard's view; whole=True: the window covers every body (phases that read only m and x)."""
@@ -102,16 +110,17 @@ class ShardedAllPairs:
         """The one collective of the path: all ranks end up with every rank's updated position shard."""
         if not self.exchange:
             return
+        if self.comm is not None:   # in place on x, stream-ordered after K3 (RCCL behind the C ABI)
+            self.comm.allgather_positions(self.state(), self._stream())
+            return
         end = self.first + self.count
-        if self.equal:
-            self.send.copy_(self.x[self.first:end])
-            self.dist.all_gather_into_tensor(self.x, self.send)
-        else:  # uneven shards: one broadcast per owner
-            for r in range(self.world):
-                f, e = shard_range(self.n, r, self.world)
-                self.dist.broadcast(self.x[f:e], src=r)
+        self.send[:self.count].copy_(self.x[self.first:end])
+        self.dist.all_gather_into_tensor(self.recv, self.send)
+        for r, (f, e) in enumerate(self.shards):
+            if r != self.rank:
+                self.x[f:e].copy_(self.recv[r * self.maxc:r * self.maxc + (e - f)])
 
-    def step(self, force_events=None):
+    def step(self, force_events=None, exchange_events=None):
         st, stream = self.state(), self._stream()
         if force_events:
             force_events[0].record()
@@ -119,7 +128,11 @@ class ShardedAllPairs:
         if force_events:
             force_events[1].record()
         self.ops.accelerate_step(st, stream)
+        if exchange_events:
+            exchange_events[0].record()
         self.exchange_positions()
+        if exchange_events:
+            exchange_events[1].record()
 
     def gather_state(self):
         """Full (x, v, a) on every rank as numpy, for checks: v and a are gathered too (test/diagnostic only)."""
@@ -135,7 +148,9 @@ class ShardedAllPairs:
         return x, outs[0], outs[1]
 
     def describe(self):
-        return f"rank shard {self.count} of {self.n} targets, all-gather {'into_tensor' if self.equal else 'per-owner broadcast'}"
+        how = ("nbody_allgather_positions (" + ("ncclAllGather in place" if self.equal else "grouped ncclSend/ncclRecv") + ")"
+               if self.comm is not None else "torch.distributed all_gather over padded shards")
+        return f"rank shard {self.count} of {self.n} targets, exchange: {how}"
 
 
 class ShardedOctree(ShardedAllPairs):
@@ -149,6 +164,15 @@ class ShardedOctree(ShardedAllPairs):
         super().__init__(hs, rank, world, **kw)
         self.theta = float(theta)
         self.tree = self.ops.octree_create(self.dtype, self.dim, self.n)
+        self.steps_done = 0
+
+    CHECK_EVERY = 64
+
+    def check(self):
+        """Raises if any build or walk since the last check flagged trouble (nbody_octree_info): a flagged build drops
+        mass, so a run must not integrate on.  Called every CHECK_EVERY steps; call it once more after the last step."""
+        if hasattr(self.tree, "info"):
+            self.tree.info(self._stream())
 
     def step(self, force_events=None):
         st, whole, stream = self.state(), self.state(whole=True), self._stream()
@@ -159,6 +183,9 @@ class ShardedOctree(ShardedAllPairs):
             force_events[1].record()
         self.ops.accelerate_step(st, stream)
         self.exchange_positions()
+        self.steps_done += 1
+        if self.steps_done % self.CHECK_EVERY == 0:
+            self.check()
 
     def describe(self):
         return "octree: tree rebuilt on every rank, " + super().describe()

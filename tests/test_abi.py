@@ -76,3 +76,40 @@ def test_no_cpu_fallback_in_product(nb):
     finally:
         nb.LIB_PATH = saved
         nb._lib = None
+
+
+def test_bench_launcher_needs_the_gpus_it_is_asked_for():
+    """`python bench.py --gpus 2` as typed: with fewer HIP devices than ranks the parent says so and exits non-zero
+    before starting anything (here: a box with no GPU at all)."""
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer than 2 GPUs")
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and not r.stdout.strip()
+
+
+def test_shard_range_matches_python(nb):
+    for n in (1, 7, 301, 1 << 20, 1000003):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                assert nb.shard_range(n, r, w) == nb.parallel.shard_range(n, r, w)
+
+
+def test_smem_pipeline_registers_untouched_in_flight(nb):
+    """K1's scalar-stream loop requests the next 16-SGPR batch with inline-asm s_load_dwordx16 one compute phase before it
+    waits for it (csrc/common.hpp sload16/swait).  Nothing but the register allocator's cooperation keeps other
+    instructions off that range while it is in flight, so the shipped code object is disassembled and checked along
+    its control-flow graph (tools/check_smem_pipeline.py)."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("check_smem_pipeline", os.path.join(ROOT, "tools", "check_smem_pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    loads, problems = mod.check(nb.LIB_PATH)
+    assert loads >= 64, f"only {loads} s_load_dwordx16 found: K1's scalar-stream kernels are missing from the disassembly"
+    assert not problems, "\n".join(problems[:10])

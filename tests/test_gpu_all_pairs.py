@@ -45,8 +45,9 @@ def test_all_pairs_force_vs_oracle(nb, oracle, dtype, dim):
 
 
 def test_pair_term_accuracy(nb, oracle):
-    """split=1 sums in the reference's order, so what is left is the pair math.  Bound of the default second-order polish:
-    [-2e-15, +4.1e-15] per term (csrc/common.hpp); measured 1.9e-15 on accelerations with no bias."""
+    """split=1 sums in the reference's order, so what is left is the pair math.  K1's far form (r2 >= 2^-16, third-order
+    step on the cube of the v_rsq seed, no reciprocal) carries rounding error only: <= 2.5 ulp per term (csrc/common.hpp);
+    the sum over 4098 terms in the same order then agrees with the oracle to ~1e-15 with no bias."""
     ref = oracle.build_model(1, 3, "galaxy", 4099)
     dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 4099))
     nb.configure_all_pairs(1, 1)
@@ -54,12 +55,44 @@ def test_pair_term_accuracy(nb, oracle):
     nb.configure_all_pairs(0, 0)
     oracle.all_pairs_force(ref)
     a = dev.download().a
-    assert maxrel(a, ref.a) <= 4.5e-15
+    assert maxrel(a, ref.a) <= 2e-15
     na, nr = np.linalg.norm(a, axis=1), np.linalg.norm(ref.a, axis=1)
-    assert abs(np.mean((na - nr) / nr)) <= 5e-16  # no systematic bias
+    assert abs(np.mean((na - nr) / nr)) <= 2e-16  # no systematic bias
 
 
-@pytest.mark.parametrize("n", [6000, 70001])  # 70001: the 8-slice scalar-stream form (sz >= 65536), windows of every size class
+def test_pair_term_two_body_ulps(nb, oracle):
+    """One source, one target: the kernel's pair term against the oracle's pow/divide expression, over separations that
+    straddle the far/near switch of K1 (r2 = 2^-16, r = 2^-8) and the range where the reference's `+ eps` matters."""
+    rng = np.random.default_rng(23)
+    worst = 0.0
+    for _ in range(6):
+        n = 2048
+        hs = nb.HostSystem(1, 3, n)
+        # pairs (2k, 2k+1) at separation r_k, pairs far apart from each other so that one term dominates each sum
+        r = np.concatenate([2.0 ** rng.uniform(-14, 6, n // 2 - 64), 2.0 ** -8 * (1 + rng.uniform(-1e-6, 1e-6, 64))])
+        base = np.arange(n // 2)[:, None] * np.array([[1e9, 0, 0]])
+        dirs = rng.standard_normal((n // 2, 3))
+        dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+        hs.x[0::2] = base
+        hs.x[1::2] = base + dirs * r[:, None]
+        hs.m[:] = 10.0 ** rng.uniform(-3, 3, n)
+        hs.c, hs.dt = 1.0, 0.1
+        ref = oracle.State(1, 3, n)
+        ref.m[:], ref.x[:], ref.c = hs.m, hs.x, 1.0
+        dev = nb.DeviceSystem.from_host(hs)
+        nb.configure_all_pairs(1, 1)
+        dev.all_pairs_force()
+        nb.configure_all_pairs(0, 0)
+        oracle.all_pairs_force(ref)
+        a = dev.download().a
+        mag = np.abs(ref.a).max(axis=1)
+        worst = max(worst, (np.abs(a - ref.a).max(axis=1) / mag).max())
+        dev.close()
+    assert worst <= 1.2e-15, worst  # a few ulp (2.2e-16 each, kernel + oracle): rounding only, on both sides of the switch
+
+
+# 70001, 100000: the 8-slice scalar-stream form with source chunks (sz >= 65536), windows of every size class
+@pytest.mark.parametrize("n", [6000, 70001, 100000])
 def test_shard_windows_are_bitwise_identical(nb, n):
     """Multi-GPU property on one GPU: any split of the targets into shard windows gives bitwise the full result."""
     dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
@@ -220,6 +253,65 @@ def test_config2_full_size_properties(nb, oracle):
 def test_config5_n_2pow20_sample(nb, oracle):
     """BASELINE metric size: 3D double N=2^20 on one GPU, oracle on a target sample."""
     _sample_check(nb, oracle, 1, 3, "galaxy", 1 << 20, "all_pairs_force", nsample=64)
+
+
+def test_config5_rank_windows_at_2pow20(nb, oracle):
+    """BASELINE config[4] as each of its 8 ranks launches it: a 131 072-target window with first = k * 131072 at
+    sz = 2^20.  Bitwise the rows of the single-GPU run (so any GPU count gives one trajectory), and within 1e-12 of the
+    oracle on a sample of the window's targets against all 2^20 sources."""
+    n, w = 1 << 20, 1 << 17
+    hs = nb.build_model(1, 3, "galaxy", n)
+    dev = nb.DeviceSystem.from_host(hs)
+    dev.all_pairs_force()
+    full = dev.download().a.copy()
+    dev.close()
+    ref = oracle.State(1, 3, n)
+    ref.m[:], ref.x[:], ref.c = hs.m, hs.x, hs.c
+    rng = np.random.default_rng(5)
+    for k in (0, 3, 7):
+        assert nb.shard_range(n, k, 8) == (k * w, (k + 1) * w)
+        d2 = nb.DeviceSystem.from_host(hs)
+        st = d2.state(k * w, w)
+        assert "R=2,JS=8" in nb.describe_all_pairs(st)
+        d2.all_pairs_force(k * w, w)
+        got = d2.download().a
+        assert np.array_equal(got[k * w:(k + 1) * w], full[k * w:(k + 1) * w]), k
+        assert not got[:k * w].any() and not got[(k + 1) * w:].any()   # nothing outside the window was written
+        picks = np.unique(np.concatenate([rng.integers(k * w, (k + 1) * w, 24), [k * w, (k + 1) * w - 1]]))
+        for i in picks:
+            oracle.all_pairs_force(ref, int(i), 1)
+        scale = np.abs(ref.a[picks]).max()
+        assert np.abs(got[picks] - ref.a[picks]).max() <= FORCE_TOL[1] * scale, k
+        d2.close()
+
+
+def test_per_context_tuning_and_describe(nb):
+    """The K1 launch shape is a property of the context (nbody_state.tuning), not of the process: two contexts with
+    different settings coexist, each equals the process-wide setting of the same values, and describe() names the launch."""
+    n = 5000
+    res = {}
+    for split, tpt, path in ((1, 1, 1), (4, 2, 2)):
+        nb.configure_all_pairs(split, tpt, source_path=path)
+        d = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+        d.all_pairs_force()
+        res[(split, tpt, path)] = d.download().a.copy()
+        d.close()
+    nb.configure_all_pairs(0, 0, source_path=0)
+    da = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    db = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    da.configure_all_pairs(1, 1, 1)
+    db.configure_all_pairs(4, 2, 2)
+    assert da.state().tuning == nb.tuning(1, 1, 1) and db.state().tuning == nb.tuning(4, 2, 2)
+    assert nb.describe_all_pairs(da.state()).startswith("all_pairs_force_kernel<double,3,R=1,JS=1>")
+    assert nb.describe_all_pairs(db.state()).startswith("all_pairs_force_sgpr_kernel<double,3,R=2,JS=4>")
+    st_a, st_b = da.state(), db.state()
+    lib = nb.lib()
+    import ctypes as C
+    assert lib.nbody_all_pairs_force(C.byref(st_b), C.c_void_p(db.stream)) == 0
+    assert lib.nbody_all_pairs_force(C.byref(st_a), C.c_void_p(da.stream)) == 0
+    assert np.array_equal(da.download().a, res[(1, 1, 1)]) and np.array_equal(db.download().a, res[(4, 2, 2)])
+    big = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 1 << 17))
+    assert "chunks=" in nb.describe_all_pairs(big.state()) and "JS=8" in nb.describe_all_pairs(big.state())
 
 
 def test_edge_cases(nb):

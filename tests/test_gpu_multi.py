@@ -1,0 +1,110 @@
+"""GPU: the multi-rank path of BASELINE config[4] exercised on the one-GPU box — bench.py's self-launcher (parent starts
+fresh rank processes through torch.distributed.run and relays rank 0's JSON line), the RCCL process group, and the
+library's own collective (nbody_comm_* / nbody_allgather_positions) at world size 1.  More than one rank needs more than
+one GPU (RCCL refuses two ranks on one device); the partition logic for world > 1 is covered on CPU by
+tests/test_sharded_gloo.py and the per-rank launch shape by test_config5_rank_windows_at_2pow20."""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench(extra_env, *args):
+    env = dict(os.environ)
+    env.update(extra_env)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout  # stdout carries exactly one line
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_forced_dist_matches_plain_run():
+    """`python bench.py --gpus 1` through the launcher (NBODY_BENCH_FORCE_DIST=1: parent -> torch.distributed.run -> rank 0,
+    RCCL process group, nbody_comm, barrier, all-gather, max-reduce) reports the same workload, kernel and — within the
+    box's run-to-run spread — the same rate as the plain single-process run."""
+    args = ("--gpus", "1", "--steps", "2", "--warmup", "1", "--bodies", str(1 << 17), "--no-cpu-baseline")
+    plain = _bench({}, *args)
+    forced = _bench({"NBODY_BENCH_FORCE_DIST": "1"}, *args)
+    assert plain["rccl_world"] is None and plain["n_gpus"] == 1
+    rw = forced["rccl_world"]
+    assert rw["world"] == 1 and rw["backend"] == "nccl" and "nbody_comm" in rw["data_path"]
+    assert forced["shards"] == [1 << 17] and plain["shards"] == [1 << 17]
+    assert forced["allgather"]["sent_bytes_per_rank_per_step"] == (1 << 17) * 24
+    assert forced["allgather"]["avg_ms"] is not None and forced["allgather"]["avg_ms"] < 5.0
+    for k in ("metric", "unit", "dtype", "scaling", "steps", "warmup"):
+        assert plain[k] == forced[k], k
+    assert plain["roofline"]["kernel"] == forced["roofline"]["kernel"]
+    assert plain["config"]["n_bodies"] == forced["config"]["n_bodies"] == 1 << 17
+    assert abs(forced["value"] / plain["value"] - 1.0) < 0.15, (forced["value"], plain["value"])
+    assert 0.2 < plain["roofline"]["frac"] < 0.7
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    have = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(have + 1), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "visible" in r.stderr and not r.stdout.strip()
+
+
+def test_comm_world1_allgather_and_partition(nb):
+    """nbody_comm at world 1 on RCCL: create from a unique id, the all-gather is the identity, a state whose window is not
+    the rank's partition is rejected; nbody_shard_range is the partition sharded.py uses."""
+    import torch
+    assert nb.Comm.rccl_version() > 20000
+    comm = nb.Comm(1, 0, nb.Comm.unique_id(), 0)
+    hs = nb.build_model(1, 3, "galaxy", 5000)
+    sim = nb.parallel.ShardedAllPairs(hs, 0, 1, torch_device=torch.device("cuda", 0), force_exchange=True, comm=comm)
+    ref = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 5000))
+    for _ in range(3):
+        sim.step()
+    nb.run(ref, "all-pairs", 3)
+    torch.cuda.synchronize()
+    x, v, a = sim.gather_state()
+    out = ref.download()
+    assert np.array_equal(x, out.x) and np.array_equal(v, out.v) and np.array_equal(a, out.a)
+    st = sim.state()
+    st.first, st.count = 10, 100
+    rc = nb.lib().nbody_allgather_positions(comm.h, C.byref(st), None)
+    assert rc == 1 and b"owns" in nb.lib().nbody_last_error()
+    comm.close()
+    for n in (7, 5000, 1 << 20, 1000003):
+        for w in (1, 2, 3, 8):
+            for r in range(w):
+                assert nb.shard_range(n, r, w) == nb.parallel.shard_range(n, r, w)
+
+
+def test_sharded_context_download_places_rows(nb):
+    """nbody_ctx_set_shard: the context's view is the window, v/a/ao point at the owned rows, download writes the owned rows
+    only — the form the CLI's --gpus N drives one context per device with."""
+    n = 6000
+    hs = nb.build_model(1, 3, "galaxy", n)
+    whole = nb.DeviceSystem.from_host(hs)
+    nb.run(whole, "all-pairs", 1)
+    ref = whole.download()
+    parts = []
+    for r in range(3):
+        d = nb.DeviceSystem.from_host(hs)
+        f, e = nb.shard_range(n, r, 3)
+        d.set_shard(f, e - f)
+        st = d.state()
+        assert (st.first, st.count, st.sz) == (f, e - f, n)
+        assert nb.lib().nbody_all_pairs_force(C.byref(st), C.c_void_p(d.stream)) == 0
+        assert nb.lib().nbody_accelerate_step(C.byref(st), C.c_void_p(d.stream)) == 0
+        parts.append((d, f, e))
+    out = nb.HostSystem(1, 3, n)
+    for d, f, e in parts:
+        nb._check(nb.lib().nbody_download(d.h, nb._p(out.m), nb._p(out.x), nb._p(out.v), nb._p(out.a), nb._p(out.ao)))
+    assert np.array_equal(out.x, ref.x) and np.array_equal(out.v, ref.v) and np.array_equal(out.a, ref.a)

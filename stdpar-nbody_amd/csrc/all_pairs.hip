@@ -30,6 +30,7 @@
 #include "common.hpp"
 
 #include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -391,6 +392,14 @@ static int plan_all_pairs(const nbody_state* s, k1_plan* out) {
   // its single-chunk order) and only in the scalar-stream form
   p.tiles_per_chunk = (s->sz + kTileJ - 1) / kTileJ;
   if (p.scalar && cfg.split == 0 && p.js == 8) ap_auto_chunks(s->sz, &p.chunks, &p.tiles_per_chunk);
+  if (const char* e = getenv("NBODY_K1_CHUNKS"); e && p.scalar) {  // experiments only (tools/tune_all_pairs.py): changes the rounding order
+    const uint32_t ntiles = (s->sz + kTileJ - 1) / kTileJ;
+    uint32_t y            = uint32_t(atoi(e));
+    if (y >= 1 && y <= ntiles) {
+      p.tiles_per_chunk = (ntiles + y - 1) / y;
+      p.chunks          = (ntiles + p.tiles_per_chunk - 1) / p.tiles_per_chunk;
+    }
+  }
   if (p.r == 0) {
     // R = 2 halves the scalar-cache traffic per pair and the block count; it pays once the grid is many rounds deep.
     const uint64_t blocks_r2 = (uint64_t(s->count) + 127) / 128 * p.chunks;
@@ -539,23 +548,6 @@ __device__ __forceinline__ double dpp_get(double v) {
 }
 
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
-  v += dpp_get<0xB1>(v);        // quad_perm:[1,0,3,2]
-  v += dpp_get<0x4E>(v);        // quad_perm:[2,3,0,1]
-  v += dpp_get<0x141>(v);       // row_half_mirror
-  v += dpp_get<0x140>(v);       // row_mirror       -> every lane of a row holds its row's sum
-  v += dpp_get<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
-  v += dpp_get<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the total
-  if constexpr (sizeof(T) == 4) {
-    return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-  } else {
-    const long long b = __builtin_bit_cast(long long, v);
-    const int lo = __builtin_amdgcn_readlane(int(b), 63), hi = __builtin_amdgcn_readlane(int(b >> 32), 63);
-    return __builtin_bit_cast(T, (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));
-  }
-}
-
-template <typename T>
 __device__ __forceinline__ T lane_bcast(T v, int src) {  // src is wave-uniform
   if constexpr (sizeof(T) == 4) {
     return __builtin_bit_cast(T, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), src));
@@ -567,7 +559,59 @@ __device__ __forceinline__ T lane_bcast(T v, int src) {  // src is wave-uniform
   }
 }
 
-template <typename T, int D>
+// Transposed wavefront reduction.  Every lane holds NT partial sums p[0..NT-1] (one per target of a group); on return
+// lane l holds, in p[0], the sum over ALL 64 lanes of partial number (l % NT).  One halving stage pairs each lane with a
+// partner on the other side of one lane-index bit (row_mirror: l^15, row_half_mirror: l^7, quad_perm: l^2, l^1 — all
+// plain DPP row operations on the VALU data path); a lane passes the half of its partials the partner keeps and adds
+// what it receives to the half it keeps, so a stage over 2m partials costs m DPP adds + 2m selects and the whole row
+// part NT - 1 DPP adds — against 6 DPP adds + a v_readlane PER partial for one wave_sum each (the form this replaces:
+// 96 vs 15 cross-lane adds per 16 targets and component).  The remaining factor 64 / NT is summed with full-wave
+// exchanges (lane ^ 8 by row_ror:8, lane ^ 16 and ^ 32 through ds_bpermute: 2-3 per group).
+template <typename T>
+__device__ __forceinline__ T xor_lane_add(T v, int mask) {  // v + v of lane (l ^ mask), mask in {16, 32}
+  return v + __shfl_xor(v, mask, 64);
+}
+
+template <typename T, int NT>
+__device__ __forceinline__ T transpose_reduce(T (&p)[NT], int lane) {
+  static_assert(NT == 16 || NT == 8, "groups of 16 (f32) or 8 (f64) targets");
+  if constexpr (NT == 16) {
+    const bool up = (lane & 8) != 0;  // row_mirror: l <-> 15 - l
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const T send = up ? p[i] : p[i + 8], keep = up ? p[i + 8] : p[i];
+      p[i]         = keep + dpp_get<0x140>(send);
+    }
+  }
+  {
+    const bool up = (lane & 4) != 0;  // row_half_mirror: l <-> l ^ 7
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T send = up ? p[i] : p[i + 4], keep = up ? p[i + 4] : p[i];
+      p[i]         = keep + dpp_get<0x141>(send);
+    }
+  }
+  {
+    const bool up = (lane & 2) != 0;  // quad_perm:[2,3,0,1]: l <-> l ^ 2
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T send = up ? p[i] : p[i + 2], keep = up ? p[i + 2] : p[i];
+      p[i]         = keep + dpp_get<0x4E>(send);
+    }
+  }
+  {
+    const bool up = (lane & 1) != 0;  // quad_perm:[1,0,3,2]: l <-> l ^ 1
+    const T send  = up ? p[0] : p[1], keep = up ? p[1] : p[0];
+    p[0]          = keep + dpp_get<0xB1>(send);
+  }
+  T v = p[0];  // sum over the lane's NT-lane group of partial (lane % NT)
+  if constexpr (NT == 8) v += dpp_get<0x128>(v);  // row_ror:8: l <-> l ^ 8
+  v = xor_lane_add(v, 16);
+  v = xor_lane_add(v, 32);
+  return v;
+}
+
+template <typename T, int D, int NT>  // NT: targets reduced together (NT * D partial sums live per lane)
 __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                                      T* __restrict__ a, T c, uint32_t sz,
                                                                      uint32_t tiles_per_block) {
@@ -586,10 +630,10 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
   T xt[D], mine[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
-    xt[k]   = x[uint64_t(ivalid ? imy : 0u) * D + k];
+    xt[k]   = x[uint64_t(ivalid ? imy : 0u) * D + k];  // lanes past the end hold body 0's position: computed, never stored
     mine[k] = T(0);
   }
-  const int ntargets = (i0 < sz) ? int(min(64u, sz - i0)) : 0;  // wave-uniform
+  const int ngroups = (i0 < sz) ? int((min(64u, sz - i0) + NT - 1) / NT) : 0;  // wave-uniform
 
   const uint32_t ntiles = (sz + TJ - 1) / TJ;
   const uint32_t t0     = blockIdx.y * tiles_per_block;
@@ -621,19 +665,25 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
 #pragma unroll
     for (int q = 0; q < KJ; ++q) src[q] = tile[q * 64 + lane];
 
-    for (int tt = 0; tt < ntargets; ++tt) {
-      T xi[D], part[D];
+    for (int g = 0; g < ngroups; ++g) {
+      T part[D][NT];
 #pragma unroll
-      for (int k = 0; k < D; ++k) {
-        xi[k]   = lane_bcast(xt[k], tt);
-        part[k] = T(0);
+      for (int tt = 0; tt < NT; ++tt) {
+        T xi[D], pt[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          xi[k] = lane_bcast(xt[k], g * NT + tt);
+          pt[k] = T(0);
+        }
+#pragma unroll
+        for (int q = 0; q < KJ; ++q) pair_accumulate<T, D>(pt, xi, src[q]);
+#pragma unroll
+        for (int k = 0; k < D; ++k) part[k][tt] = pt[k];
       }
 #pragma unroll
-      for (int q = 0; q < KJ; ++q) pair_accumulate<T, D>(part, xi, src[q]);
-#pragma unroll
       for (int k = 0; k < D; ++k) {
-        T tot = wave_sum(part[k]);
-        if (lane == tt) mine[k] += tot;
+        const T tot = transpose_reduce<T, NT>(part[k], lane);  // lane l: target g*NT + l % NT, summed over the wave
+        mine[k] += (lane / NT == g) ? tot : T(0);
       }
     }
   }
@@ -661,9 +711,16 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   if (ysplit > 65535) ysplit = 65535;
   uint32_t tpb = (ntiles + ysplit - 1) / ysplit;
   ysplit       = (ntiles + tpb - 1) / tpb;
-  hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
-                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
-                     s->sz, tpb);
+  int nt = sizeof(T) == 4 ? 16 : 8;
+  if (const char* e = getenv("NBODY_K2_NT")) nt = atoi(e) == 16 ? 16 : 8;  // experiments only (tools/time_collapsed.py)
+  if (nt == 16)
+    hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, 16>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
+                       s->sz, tpb);
+  else
+    hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, 8>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
+                       s->sz, tpb);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }

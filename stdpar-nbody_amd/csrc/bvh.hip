@@ -373,34 +373,50 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
 // ------------------------------------------------------------------------------------------------
 // K9 traversal  (src/bvh.h:246-324)
 // ------------------------------------------------------------------------------------------------
+// One entry against one body, shared by both scheduling forms (so they stay bitwise identical):
+//   d = xs - p          the reference's operand order in can_approximate / dist2 (src/vec.h:232-240);
+//   d2                  dist2 summed exactly as the reference does — separate multiply and add, ascending k — because the
+//                       opening test  bw*bw < theta^2 * d2  (src/bvh.h:246-248) must decide bit for bit like it;
+//   term                m * (p - xs) / dist3 (src/bvh.h:297,308) = -w * d.  In f64 the weight comes from the test's own d2
+//                       (one rounding per product instead of fused: 1e-16 relative, the force is tolerance parity) through
+//                       K1's reciprocal-free weight_far; only if some lane of the wave holds an accepted entry closer than
+//                       2^-8 (the body's own leaf, coincident bodies) does the wave also evaluate the guarded form from the
+//                       fused r2 (+tiny, so that d = 0 gives exactly 0) and each lane keeps what its own d2 asks for.
+//                       f32 keeps weight() on the fused r2 (1-ulp hardware seeds, nothing to gain).
 template <typename T, int D>
-__device__ __forceinline__ bool can_approximate(const T (&xs)[D], const tree_rec<T>& nd, T theta2) {
+__device__ __forceinline__ T dist2_ref(const T (&d)[D]) {
 #pragma clang fp contract(off)
-  T d2 = T(0);  // dist2(xs, xj), src/vec.h:232-240: separate multiply and add, in the reference's order
+  T d2 = d[0] * d[0];  // 0 + d0*d0 of the reference: exact
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    T di = xs[k] - nd.v[k];
-    d2   = d2 + di * di;
-  }
-  return nd.v[D + 2] < theta2 * d2;  // bw*bw < theta^2 * dist2, src/bvh.h:246-248
+  for (int k = 1; k < D; ++k) d2 = d2 + d[k] * d[k];
+  return d2;
 }
 
-// acc += m * (p - xs) / dist3 for a node's monopole (src/bvh.h:308) or a body (src/bvh.h:297): same expression
+// `take_mask` = ballot(take), handed in by the caller: wave-uniform conditions are kept as scalar masks built from
+// ballots of plain compares (a ballot of a derived boolean costs hipcc a v_cndmask + v_cmp round trip).
 template <typename T, int D>
-__device__ __forceinline__ void accumulate_entry(T (&acc)[D], const T (&xs)[D], const tree_rec<T>& e) {
-  src_rec<T, D> s;
+__device__ __forceinline__ void tree_accumulate(bool take, uint64_t take_mask, T (&acc)[D], const T (&d)[D], T d2, T m,
+                                                const pair_consts<T>& pc) {
+  T w;
+  if constexpr (sizeof(T) == 8) {
+    w                 = pair_math<T>::weight_far(d2, m, pc.k15, pc.k1875);
+    const bool close  = uint32_t(__builtin_bit_cast(unsigned long long, d2) >> 32) < pair_math<T>::near_hi;
+    if (__builtin_expect((__builtin_amdgcn_ballot_w64(close) & take_mask) != 0ull, 0)) {
+      T r2 = pair_math<T>::tiny;
 #pragma unroll
-  for (int k = 0; k < D; ++k) s.p[k] = e.v[k];
-  s.m = e.v[D];
-  pair_accumulate<T, D>(acc, xs, s);
-}
-template <typename T, int D>
-__device__ __forceinline__ void accumulate_entry_if(bool take, T (&acc)[D], const T (&xs)[D], const tree_rec<T>& e) {
-  src_rec<T, D> s;
+      for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+      const T wn = pair_math<T>::template weight<3>(r2, m);
+      w          = close ? wn : w;
+    }
+  } else {
+    T r2 = pair_math<T>::tiny;
 #pragma unroll
-  for (int k = 0; k < D; ++k) s.p[k] = e.v[k];
-  s.m = e.v[D];
-  pair_accumulate_if<T, D>(take, acc, xs, s);
+    for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
+    w = pair_math<T>::weight(r2, m);
+  }
+  w = take ? w : T(0);  // predicated weight, not control flow: the accumulators stay in place (see pair_accumulate_if)
+#pragma unroll
+  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(-w, d[k], acc[k]);
 }
 
 // XCD-aware block order.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an L2), while
@@ -424,6 +440,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
   const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (local >= count) return;
   const uint32_t i = first + local;
+  const pair_consts<T> pc;
   T xs[D], acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -436,8 +453,16 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 
   while (covered < sz) {
     const bool body = level == nlevels;
+    T d[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[k] = xs[k] - rec.v[k];
+    const T d2 = dist2_ref<T, D>(d);
     // decision: a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
-    const bool take = body || can_approximate<T, D>(xs, rec, theta2);
+    bool take;
+    {
+#pragma clang fp contract(off)
+      take = body || rec.v[D + 2] < theta2 * d2;
+    }
     uint32_t n_index, n_level = level, n_cov = covered;
     if (take) {
       n_cov = covered + (1u << (nlevels - level));
@@ -464,7 +489,8 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
         c_mono += take;
       }
     }
-    if (take) accumulate_entry<T, D>(acc, xs, rec);  // the self pair adds exactly 0
+    const uint64_t take_mask = __builtin_amdgcn_ballot_w64(take);
+    if (take_mask != 0ull) tree_accumulate<T, D>(take, take_mask, acc, d, d2, rec.v[D], pc);  // the self pair adds exactly 0
     rec        = nrec;
     tree_index = n_index;
     level      = n_level;
@@ -489,25 +515,57 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // first body — and along any lane's walk that key only grows in (covered, level) lexicographic order, which is
 // DFS pre-order.  The wave therefore sweeps the UNION of its 64 lanes' entries once, in key order: at each step
 // the record is wave-uniform (one scalar load instead of 64 divergent gathers), lanes whose key equals the
-// current one take part, the others wait.  Lanes cannot drift apart.  Union per wave at config 4: ~7.5k entries
+// current one take part, the others wait.  Lanes cannot drift apart.  Union per wave at config 4: ~7.0k entries
 // vs ~4.3k per lane, so with few waves in flight (small N) the per-lane form is faster.
-// This form is bound by its serial chain and the CU's single scalar unit (~50 SALU instructions per step).
-// Measured and rejected: fetching both possible successors speculatively (scalar loads return out of order,
+// This form is bound by its serial chain and by issue slots — of the FP64 pipe and of the CU's one scalar unit,
+// which serves its four SIMDs in turn — so the step is written to be short in both:
+//   * the whole 64-byte record arrives with ONE s_load_dwordx16 whose address is base + a byte offset kept in an
+//     SGPR (off = 64 * level-order index: child = 2*off + 64, sibling = off + 64, parent + 1 = off / 2);
+//   * the sweep position is the packed key cur = covered << 5 | level plus shift = nlevels - level; both successors
+//     are one or two scalar operations away (descend: cur + 1; ascend: cur + (32 << shift) - right);
+//   * the opening test's differences are reused by the accepted term, whose weight needs no reciprocal (tree_accumulate).
+// Measured and rejected earlier: fetching both possible successors speculatively (scalar loads return out of order,
 // so every step waits for the not-taken, often cold, one: 26 vs 14 ms); a wave-private LDS window over a
 // pre-order copy of the tree filled by LDS-DMA (15.6 ms: refills cost more than the misses they replace);
-// pipelining the next record's load ahead of the accumulation as in the per-lane kernel (18.7 ms with SGPR record
-// copies, which overload the scalar unit; 15.6 ms with ping-pong record registers and no copies — still no gain).
+// pipelining the next record's load ahead of the accumulation as in the per-lane kernel.
 // Packed key = covered << 5 | level, so this form needs nlevels <= 26.
 // ------------------------------------------------------------------------------------------------
+template <typename T>
+struct rec_sgprs;
+template <>
+struct rec_sgprs<double> {
+  typedef uint32_t type __attribute__((ext_vector_type(16)));
+  __device__ static __forceinline__ type load(const void* base, uint32_t off) {  // base, off wave-uniform
+    type r;
+    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(base), "s"(off));
+    return r;
+  }
+};
+template <>
+struct rec_sgprs<float> {
+  typedef uint32_t type __attribute__((ext_vector_type(8)));
+  __device__ static __forceinline__ type load(const void* base, uint32_t off) {
+    type r;
+    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(base), "s"(off));
+    return r;
+  }
+};
+template <typename V>
+__device__ __forceinline__ void rec_wait(V& v) {
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
+}
+
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
                                                             uint32_t* __restrict__ counters) {
   constexpr uint32_t DONE = 0xffffffffu;
+  constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
   const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid     = local < count;
   const uint32_t i     = first + (valid ? local : 0u);
+  const pair_consts<T> pc;
   T xs[D], acc[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -519,44 +577,42 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   uint32_t key = valid ? 0u : DONE;  // root: covered 0, level 0
   uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
 
-  // wave-uniform position of the sweep, kept incrementally (the scalar unit is this kernel's bottleneck): level,
-  // first body `cov`, level-order index `idx` of the current entry; `cur` is the same position as a packed key
-  uint32_t level = 0, cov = 0, idx = 0, cur = 0;
+  // wave-uniform position of the sweep, kept incrementally in SGPRs: packed key, levels below, byte offset of the record
+  uint32_t cur = 0, shift = nlevels, off = 0;
+  const uint32_t end_key = sz << 5;  // cur >= end_key: covered >= sz, every remaining key is >= cur: all lanes are finished
 
-  for (;;) {
-    if (cov >= sz) {  // every remaining key is >= cur: all lanes are finished
-      if (valid) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
-        if (COUNT) {
-          counters[uint64_t(i) * 4 + 0] = c_nodes;
-          counters[uint64_t(i) * 4 + 1] = c_leaf;
-          counters[uint64_t(i) * 4 + 2] = c_mono;
-          counters[uint64_t(i) * 4 + 3] = c_body;
-        }
-      }
-      return;
-    }
-    const tree_rec<T> rc = node[idx];  // wave-uniform address: one scalar load
-
-    // the two possible successors
-    const uint32_t shift = nlevels - level;  // 0 on the body level
-    const uint32_t span  = 1u << shift;
-    const uint32_t ncov  = cov + span;
+  while (cur < end_key) {
+    auto raw = rec_sgprs<T>::load(node, off);  // wave-uniform address: one scalar load of the whole record
+    // the two possible successors while the load is in flight
     // left child -> sibling (same level); right child -> parent + 1 (level - 1)   (src/bvh.h:272-281)
     // (an entry is a right child iff its level-order index is even; the root counts as one)
-    const bool right    = (idx & 1u) == 0u;
-    const uint32_t nlev = right ? level - 1u : level;
-    const uint32_t ka   = (ncov << 5) | (nlev & 31u);
-    const uint32_t kd   = cur + 1u;  // descend: same covered, level + 1  (src/bvh.h:283-286)
-
-    const bool body   = shift == 0u;
-    const bool active = key == cur;
+    const uint32_t right = ((off / RB) & 1u) ^ 1u;
+    const uint32_t ka    = cur + (32u << shift) - right;  // covered + 2^shift, level - right
+    const uint32_t kd    = cur + 1u;                      // descend: same covered, level + 1  (src/bvh.h:283-286)
+    const bool body      = shift == 0u;
+    const bool active    = key == cur;
+    rec_wait(raw);
+    const tree_rec<T> rc = __builtin_bit_cast(tree_rec<T>, raw);
+    T d[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[k] = xs[k] - rc.v[k];
+    const T d2 = dist2_ref<T, D>(d);
     // a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
-    const bool approx = body || can_approximate<T, D>(xs, rc, theta2);
+    bool passes;
+    {
+#pragma clang fp contract(off)
+      passes = rc.v[D + 2] < theta2 * d2;
+    }
+    const bool approx = body || passes;
     const bool accept = active && approx;
     const bool reject = active && !approx;
+    // the same conditions wave-wide, as scalar masks from ballots of the two plain compares
+    const uint64_t m_active = __builtin_amdgcn_ballot_w64(key == cur);
+    const uint64_t m_approx = __builtin_amdgcn_ballot_w64(passes) | (body ? ~0ull : 0ull);
+    const uint64_t m_accept = m_active & m_approx;
+    const uint64_t m_reject = m_active & ~m_approx;
     if (COUNT && active) {
+      const uint32_t cov = cur >> 5;
       if (body) {
         c_body += (cov != i);
         c_leaf += !(cov & 1u);  // one leaf visit per body pair, counted at its first body
@@ -565,35 +621,42 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
         c_mono += approx;
       }
     }
-    if (__ballot(accept) != 0ull) {  // wave-uniform branch, per-lane predication of the weight
-      accumulate_entry_if<T, D>(accept, acc, xs, rc);
-    }
+    if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc, d, d2, rc.v[D], pc);
     key = accept ? ka : (reject ? kd : key);
-    if (__ballot(reject) != 0ull) {
+    if (m_reject != 0ull) {
       // a lane opened the node: its left child is the smallest key any lane can now hold
       cur   = kd;
-      level = level + 1u;
-      idx   = 2u * idx + 1u;
-    } else if (__ballot(key < ka) == 0ull) {
+      shift = shift - 1u;
+      off   = 2u * off + RB;
+    } else if (__builtin_amdgcn_ballot_w64(key < ka) == 0ull) {
       // nobody is behind the finishing lanes' key: follow the ascend rule incrementally
       cur   = ka;
-      cov   = ncov;
-      idx   = right ? (idx >> 1) : idx + 1u;  // parent + 1 = (idx - 2) / 2 + 1 for an even idx ; sibling
-      level = nlev;
+      shift = shift + right;
+      off   = right ? (off >> 1) : off + RB;  // parent + 1 = idx / 2 for an even idx ; sibling
     } else {
       // some lane waits at a smaller key (it jumped here from a deeper subtree): take the smallest and decode it
       uint32_t cand   = ka;
-      uint64_t behind = __ballot(key < cand);
+      uint64_t behind = __builtin_amdgcn_ballot_w64(key < cand);
       while (behind) {
         cand   = __builtin_amdgcn_readlane(key, __builtin_ctzll(behind));
-        behind = __ballot(key < cand);
+        behind = __builtin_amdgcn_ballot_w64(key < cand);
       }
-      cur   = cand;
-      level = cand & 31u;
-      cov   = cand >> 5;
-      idx   = ((1u << level) - 1u) + (cov >> (nlevels - level));
+      cur                  = cand;
+      const uint32_t level = cand & 31u;
+      shift                = nlevels - level;
+      off                  = (((1u << level) - 1u) + ((cand >> 5) >> shift)) * RB;
     }
     cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(i) * 4 + 0] = c_nodes;
+      counters[uint64_t(i) * 4 + 1] = c_leaf;
+      counters[uint64_t(i) * 4 + 2] = c_mono;
+      counters[uint64_t(i) * 4 + 3] = c_body;
+    }
   }
 }
 

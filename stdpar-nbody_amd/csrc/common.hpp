@@ -103,8 +103,8 @@ inline int dispatch(int dtype, int dim, F&& f) {
 template <typename T>
 struct pair_math;
 
-// NBODY_PAIR_POLISH: order of the polish applied to the two 2^-24 FP64 seeds of weight() — the form used by the tree
-// walks (K9, octree) and, in K1, only for pairs closer than 2^-8 (see weight_far below).
+// NBODY_PAIR_POLISH: order of the polish applied to the two 2^-24 FP64 seeds of weight() as the tree walks (K9, octree)
+// use it.  K1 uses weight() only for pairs closer than 2^-8 (see weight_far below) and takes the third-order form there.
 //   2 (default): Newton steps  s = h + h*e/2,  w = zm + zm*e2        17 full-rate ops + 2 transcendentals per pair.
 //      Per-term error bound: +3/8*e^2 (e <= 2^-23.2) - e2^2 (e2 <= 2^-24.4)  =>  within [-2e-15, +4.1e-15] relative.
 //   3: third-order steps (+2 FMA): <= 2 ulp per term.
@@ -115,27 +115,29 @@ struct pair_math;
 template <>
 struct pair_math<double> {
   static constexpr double tiny = 1e-300;
-  // returns mj / (r2 * sqrt(r2) + DBL_EPSILON)
+  // returns mj / (r2 * sqrt(r2) + DBL_EPSILON); POLISH = order of the steps on the two seeds
+  template <int POLISH = NBODY_PAIR_POLISH>
   __device__ static __forceinline__ double weight(double r2, double mj) {
     double y0 = __builtin_amdgcn_rsq(r2);     // ~2^-24 relative
     double h  = r2 * y0;                      // ~sqrt(r2)
     double e  = __builtin_fma(-h, y0, 1.0);   // 1 - r2*y0^2
-#if NBODY_PAIR_POLISH >= 3
-    double p  = __builtin_fma(e, 0.375, 0.5);
-    double s  = __builtin_fma(h * e, p, h);   // sqrt(r2)*(1 + O(e^3))
-#else
-    double s  = __builtin_fma(h * 0.5, e, h); // sqrt(r2)*(1 - 3/8 e^2)
-#endif
+    double s;
+    if constexpr (POLISH >= 3) {
+      double p = __builtin_fma(e, 0.375, 0.5);
+      s        = __builtin_fma(h * e, p, h);   // sqrt(r2)*(1 + O(e^3))
+    } else {
+      s = __builtin_fma(h * 0.5, e, h);        // sqrt(r2)*(1 - 3/8 e^2)
+    }
     double d3 = __builtin_fma(r2, s, DBL_EPSILON);
     double z0 = __builtin_amdgcn_rcp(d3);     // ~2^-24 relative
     double e2 = __builtin_fma(-d3, z0, 1.0);
     double zm = z0 * mj;
-#if NBODY_PAIR_POLISH >= 3
-    double q  = __builtin_fma(e2, e2, e2);    // e2 + e2^2
-    return __builtin_fma(zm, q, zm);          // mj/d3 * (1 + O(e2^3))
-#else
-    return __builtin_fma(zm, e2, zm);         // mj/d3 * (1 - e2^2)
-#endif
+    if constexpr (POLISH >= 3) {
+      double q = __builtin_fma(e2, e2, e2);   // e2 + e2^2
+      return __builtin_fma(zm, q, zm);        // mj/d3 * (1 + O(e2^3))
+    } else {
+      return __builtin_fma(zm, e2, zm);       // mj/d3 * (1 - e2^2)
+    }
   }
 
   // The same quantity without the reciprocal, for r2 >= 2^-16 (K1's fast path).  With u = r2^(-3/2):
@@ -271,7 +273,7 @@ __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], 
 #pragma unroll
         for (int r = 0; r < R; ++r) {
           const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
-          const T wn        = pair_math<T>::weight(r2[u][r], s[u].m);
+          const T wn        = pair_math<T>::template weight<3>(r2[u][r], s[u].m);  // rare: take the <= 2 ulp form
           w[u][r]           = hi < pair_math<T>::near_hi ? wn : w[u][r];
         }
     }

@@ -516,10 +516,10 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
 // ------------------------------------------------------------------------------------------------
 // K2
 // ------------------------------------------------------------------------------------------------
-// sources per LDS tile: 16 per lane in f32, 8 per lane in f64 (64 VGPRs of source registers either way; 8 per lane in
-// f32 was measured slower, 34 vs 27 ms at config 3: the per-target broadcast + reduction is amortised over fewer pairs)
+// sources per LDS tile: 32 per lane in f32 (32 KB), 16 per lane in f64 (32 KB): the cross-lane reduction and the target
+// broadcasts are paid once per (NT targets x tile), so the tile is as long as the LDS budget of 3-4 blocks per CU allows
 template <typename T>
-constexpr int kColTileJ = sizeof(T) == 4 ? 1024 : 512;
+constexpr int kColTileJ = sizeof(T) == 4 ? 2048 : 1024;
 
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void collapsed_reset_kernel(T* __restrict__ a, const T* __restrict__ ao, uint64_t n) {
@@ -611,7 +611,9 @@ __device__ __forceinline__ T transpose_reduce(T (&p)[NT], int lane) {
   return v;
 }
 
-template <typename T, int D, int NT>  // NT: targets reduced together (NT * D partial sums live per lane)
+// NT: targets reduced together (NT * D partial sums live per lane); KS: source records per lane held in registers at a
+// time; NB: independent pair chains in flight
+template <typename T, int D, int NT, int KS, int NB>
 __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                                      T* __restrict__ a, T c, uint32_t sz,
                                                                      uint32_t tiles_per_block) {
@@ -660,25 +662,36 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
     }
     __syncthreads();
 
-    // my KJ sources of this tile live in registers for all 64 targets of the wave
-    rec_t src[KJ];
-#pragma unroll
-    for (int q = 0; q < KJ; ++q) src[q] = tile[q * 64 + lane];
-
+    // Per group of NT targets: the lane's KJ sources of the tile pass through registers in SUBS batches of KS (re-read from
+    // LDS per group: 64 VGPRs of sources at once left no room for independent pair chains), the NT * D partial sums
+    // stay in registers over the whole tile and are reduced across the wavefront once per (group, tile).
+    constexpr int SUBS = KJ / KS;
     for (int g = 0; g < ngroups; ++g) {
+      T xg[NT][D];  // wave-uniform: the group's target positions, broadcast into SGPRs once per tile
+#pragma unroll
+      for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+        for (int k = 0; k < D; ++k) xg[tt][k] = lane_bcast(xt[k], g * NT + tt);
       T part[D][NT];
 #pragma unroll
-      for (int tt = 0; tt < NT; ++tt) {
-        T xi[D], pt[D];
+      for (int k = 0; k < D; ++k)
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-          xi[k] = lane_bcast(xt[k], g * NT + tt);
-          pt[k] = T(0);
+        for (int tt = 0; tt < NT; ++tt) part[k][tt] = T(0);
+#pragma unroll 1
+      for (int sub = 0; sub < SUBS; ++sub) {
+        rec_t src[KS];
+#pragma unroll
+        for (int q = 0; q < KS; ++q) src[q] = tile[(sub * KS + q) * 64 + lane];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) {
+          T pt[D];
+#pragma unroll
+          for (int k = 0; k < D; ++k) pt[k] = part[k][tt];
+#pragma unroll
+          for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);
+#pragma unroll
+          for (int k = 0; k < D; ++k) part[k][tt] = pt[k];
         }
-#pragma unroll
-        for (int q = 0; q < KJ; ++q) pair_accumulate<T, D>(pt, xi, src[q]);
-#pragma unroll
-        for (int k = 0; k < D; ++k) part[k][tt] = pt[k];
       }
 #pragma unroll
       for (int k = 0; k < D; ++k) {
@@ -711,16 +724,23 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   if (ysplit > 65535) ysplit = 65535;
   uint32_t tpb = (ntiles + ysplit - 1) / ysplit;
   ysplit       = (ntiles + tpb - 1) / tpb;
-  int nt = sizeof(T) == 4 ? 16 : 8;
-  if (const char* e = getenv("NBODY_K2_NT")) nt = atoi(e) == 16 ? 16 : 8;  // experiments only (tools/time_collapsed.py)
-  if (nt == 16)
-    hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, 16>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
-                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
-                       s->sz, tpb);
-  else
-    hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, 8>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,
-                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c),
-                       s->sz, tpb);
+  // Measured at config 3 (f32, N = 262 144) and on the reference's matrix size (f64, N = 10^5), gpurun_out/r02/k2_times*.txt:
+  // every variant with ONE pair chain per lane in flight runs at 24.05 ms (36.3 % of the FP32 vector peak) whatever NT, KS
+  // and the occupancy (3 to 6 waves per SIMD); every variant that interleaves 2 or 4 chains runs at 28.7 ms — the interleaved
+  // order puts v_rsq_f32 and v_rcp_f32 back to back.  In f64 the forms differ by < 2 %; (8, 4, 4) is the fastest (7.47 ms).
+  int cfg = sizeof(T) == 4 ? 0 : 1;
+  if (const char* e = getenv("NBODY_K2_CFG")) cfg = atoi(e);  // experiments only (tools/time_collapsed.py)
+#define NB_K2(NT, KS, NBC)                                                                                              \
+  hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, NT, KS, NBC>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,        \
+                     static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), \
+                     s->sz, tpb)
+  switch (cfg) {
+    case 0: NB_K2(16, 8, 1); break;
+    case 1: NB_K2(8, 4, 4); break;
+    case 2: NB_K2(8, 4, 1); break;
+    default: NB_K2(16, 8, 4); break;
+  }
+#undef NB_K2
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }

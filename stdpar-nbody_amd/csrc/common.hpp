@@ -219,6 +219,32 @@ __device__ __forceinline__ void pair_accumulate_if(bool take, T (&acc)[D], const
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
 }
 
+// NB sources against one target, written stage by stage (all differences, all r2, all weights, then the accumulation)
+// so that NB independent dependency chains are in flight: under register pressure hipcc otherwise emits one pair after
+// the other through the same temporaries, each transcendental followed by a wait state (K2: 446 s_nop per 256 pairs).
+template <typename T, int D, int NB>
+__device__ __forceinline__ void pair_accumulate_multi(T (&acc)[D], const T (&xi)[D], const src_rec<T, D>* s) {
+  T d[NB][D], r2[NB], w[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[b][k] = s[b].p[k] - xi[k];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    r2[b] = pair_math<T>::tiny;
+#pragma unroll
+    for (int k = 0; k < D; ++k) r2[b] = __builtin_elementwise_fma(d[b][k], d[b][k], r2[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) w[b] = pair_math<T>::weight(r2[b], s[b].m);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w[b], d[b][k], acc[k]);
+  }
+}
+
 // Loop-invariant operands of pair_batch that must stay in registers (made opaque to the optimiser once, outside the loop).
 template <typename T>
 struct pair_consts {

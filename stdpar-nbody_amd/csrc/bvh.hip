@@ -555,27 +555,37 @@ __device__ __forceinline__ void rec_wait(V& v) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
 }
 
-template <typename T, int D, bool COUNT>
+// BPL bodies per lane: the wave sweeps the union of 64 * BPL consecutive (Hilbert-adjacent) bodies' walks.  The union
+// grows slowly with the group (about 7.4k entries for 64 bodies, 8k for 128 at config 4) while the scalar half of a step —
+// load, successors, position update: as many issue slots as the vector half — is paid once per step, and the BPL
+// independent per-body chains give the wave instruction-level parallelism.
+template <typename T, int D, int BPL, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
                                                             uint32_t* __restrict__ counters) {
   constexpr uint32_t DONE = 0xffffffffu;
   constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
-  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  const bool valid     = local < count;
-  const uint32_t i     = first + (valid ? local : 0u);
+  const uint32_t base = xcd_contiguous_block(blockIdx.x, gridDim.x) * (64u * BPL) + threadIdx.x;
   const pair_consts<T> pc;
-  T xs[D], acc[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xs[k]  = x[uint64_t(i) * D + k];
-    acc[k] = T(0);
-  }
+  T xs[BPL][D], acc[BPL][D];
+  uint32_t key[BPL], bi[BPL];
+  bool valid[BPL];
   // A lane's key keeps counting past the end (covered >= sz means finished: such keys compare above every live
   // one because `covered` sits in the high bits), so only lanes outside the shard need a sentinel.
-  uint32_t key = valid ? 0u : DONE;  // root: covered 0, level 0
-  uint32_t c_nodes = 0, c_leaf = 0, c_mono = 0, c_body = 0;
+#pragma unroll
+  for (int b = 0; b < BPL; ++b) {
+    const uint32_t local = base + 64u * b;
+    valid[b]             = local < count;
+    bi[b]                = first + (valid[b] ? local : 0u);
+    key[b]               = valid[b] ? 0u : DONE;  // root: covered 0, level 0
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      xs[b][k]  = x[uint64_t(bi[b]) * D + k];
+      acc[b][k] = T(0);
+    }
+  }
+  uint32_t c_nodes[BPL] = {}, c_leaf[BPL] = {}, c_mono[BPL] = {}, c_body[BPL] = {};
 
   // wave-uniform position of the sweep, kept incrementally in SGPRs: packed key, levels below, byte offset of the record
   uint32_t cur = 0, shift = nlevels, off = 0;
@@ -590,56 +600,77 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     const uint32_t ka    = cur + (32u << shift) - right;  // covered + 2^shift, level - right
     const uint32_t kd    = cur + 1u;                      // descend: same covered, level + 1  (src/bvh.h:283-286)
     const bool body      = shift == 0u;
-    const bool active    = key == cur;
     rec_wait(raw);
     const tree_rec<T> rc = __builtin_bit_cast(tree_rec<T>, raw);
-    T d[D];
+    uint64_t m_reject_any = 0ull, waiting = 0ull;
 #pragma unroll
-    for (int k = 0; k < D; ++k) d[k] = xs[k] - rc.v[k];
-    const T d2 = dist2_ref<T, D>(d);
-    // a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
-    bool passes;
-    {
+    for (int b = 0; b < BPL; ++b) {
+      T d[D];
+#pragma unroll
+      for (int k = 0; k < D; ++k) d[k] = xs[b][k] - rc.v[k];
+      const T d2 = dist2_ref<T, D>(d);
+      // a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
+      T scaled;
+      {
 #pragma clang fp contract(off)
-      passes = rc.v[D + 2] < theta2 * d2;
-    }
-    const bool approx = body || passes;
-    const bool accept = active && approx;
-    const bool reject = active && !approx;
-    // the same conditions wave-wide, as scalar masks from ballots of the two plain compares
-    const uint64_t m_active = __builtin_amdgcn_ballot_w64(key == cur);
-    const uint64_t m_approx = __builtin_amdgcn_ballot_w64(passes) | (body ? ~0ull : 0ull);
-    const uint64_t m_accept = m_active & m_approx;
-    const uint64_t m_reject = m_active & ~m_approx;
-    if (COUNT && active) {
-      const uint32_t cov = cur >> 5;
-      if (body) {
-        c_body += (cov != i);
-        c_leaf += !(cov & 1u);  // one leaf visit per body pair, counted at its first body
-      } else {
-        ++c_nodes;
-        c_mono += approx;
+        scaled = theta2 * d2;
       }
+      // the conditions as scalar masks from ballots of the two plain compares; lanes read them back for free
+      const uint64_t m_active = __builtin_amdgcn_ballot_w64(key[b] == cur);
+      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(rc.v[D + 2] < scaled) | (body ? ~0ull : 0ull);
+      const uint64_t m_accept = m_active & m_approx;
+      const uint64_t m_reject = m_active & ~m_approx;
+      const bool accept       = __builtin_amdgcn_inverse_ballot_w64(m_accept);
+      const bool reject       = __builtin_amdgcn_inverse_ballot_w64(m_reject);
+      if (COUNT) {
+        const bool active = __builtin_amdgcn_inverse_ballot_w64(m_active);
+        const bool approx = __builtin_amdgcn_inverse_ballot_w64(m_approx);
+        if (active) {
+          const uint32_t cov = cur >> 5;
+          if (body) {
+            c_body[b] += (cov != bi[b]);
+            c_leaf[b] += !(cov & 1u);  // one leaf visit per body pair, counted at its first body
+          } else {
+            ++c_nodes[b];
+            c_mono[b] += approx;
+          }
+        }
+      }
+      if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc[b], d, d2, rc.v[D], pc);
+      key[b] = accept ? ka : (reject ? kd : key[b]);
+      m_reject_any |= m_reject;
+      waiting |= __builtin_amdgcn_ballot_w64(key[b] < ka);
     }
-    if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc, d, d2, rc.v[D], pc);
-    key = accept ? ka : (reject ? kd : key);
-    if (m_reject != 0ull) {
-      // a lane opened the node: its left child is the smallest key any lane can now hold
-      cur   = kd;
-      shift = shift - 1u;
-      off   = 2u * off + RB;
-    } else if (__builtin_amdgcn_ballot_w64(key < ka) == 0ull) {
-      // nobody is behind the finishing lanes' key: follow the ascend rule incrementally
-      cur   = ka;
-      shift = shift + right;
-      off   = right ? (off >> 1) : off + RB;  // parent + 1 = idx / 2 for an even idx ; sibling
-    } else {
-      // some lane waits at a smaller key (it jumped here from a deeper subtree): take the smallest and decode it
-      uint32_t cand   = ka;
-      uint64_t behind = __builtin_amdgcn_ballot_w64(key < cand);
-      while (behind) {
-        cand   = __builtin_amdgcn_readlane(key, __builtin_ctzll(behind));
-        behind = __builtin_amdgcn_ballot_w64(key < cand);
+    // Next position, branch-free in the common cases (every branch costs the wave an issue slot and a refetch).
+    // A lane opened the node: its left child is the smallest key any lane can now hold.  Otherwise follow the ascend rule
+    // (parent + 1 = idx / 2 for an even idx; sibling = idx + 1) — unless some lane waits at a smaller key: it jumped there
+    // from a deeper subtree, to an entry below the one just accepted by the others (rare; found and decoded below).
+    const uint32_t off_down = 2u * off + RB, off_up = right ? (off >> 1) : off + RB;
+    const uint32_t sh_down = shift - 1u, sh_up = shift + right;
+    uint64_t behind;
+    // four scalar selects on one condition; written out because hipcc turns the equivalent C++ into a diamond of branches
+    asm volatile("s_cmp_lg_u64 %[mr], 0\n\t"
+                 "s_cselect_b32 %[cur], %[kd], %[ka]\n\t"
+                 "s_cselect_b32 %[off], %[od], %[ou]\n\t"
+                 "s_cselect_b32 %[sh], %[sd], %[su]\n\t"
+                 "s_cselect_b64 %[bh], 0, %[wt]"
+                 : [cur] "=&s"(cur), [off] "=&s"(off), [sh] "=&s"(shift), [bh] "=&s"(behind)
+                 : [mr] "s"(m_reject_any), [kd] "s"(kd), [ka] "s"(ka), [od] "s"(off_down), [ou] "s"(off_up), [sd] "s"(sh_down),
+                   [su] "s"(sh_up), [wt] "s"(waiting)
+                 : "scc");
+    if (__builtin_expect(behind != 0ull, 0)) {
+      uint32_t cand = ka;
+      for (bool again = true; again;) {  // the smallest key any body of the wave holds
+        again = false;
+#pragma unroll
+        for (int b = 0; b < BPL; ++b) {
+          uint64_t m = __builtin_amdgcn_ballot_w64(key[b] < cand);
+          while (m) {
+            cand  = __builtin_amdgcn_readlane(key[b], __builtin_ctzll(m));
+            m     = __builtin_amdgcn_ballot_w64(key[b] < cand);
+            again = BPL > 1;
+          }
+        }
       }
       cur                  = cand;
       const uint32_t level = cand & 31u;
@@ -648,14 +679,18 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     }
     cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR
   }
-  if (valid) {
 #pragma unroll
-    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
-    if (COUNT) {
-      counters[uint64_t(i) * 4 + 0] = c_nodes;
-      counters[uint64_t(i) * 4 + 1] = c_leaf;
-      counters[uint64_t(i) * 4 + 2] = c_mono;
-      counters[uint64_t(i) * 4 + 3] = c_body;
+  for (int b = 0; b < BPL; ++b) {
+    if (valid[b]) {
+      const uint32_t local = base + 64u * b;
+#pragma unroll
+      for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[b][k];
+      if (COUNT) {
+        counters[uint64_t(bi[b]) * 4 + 0] = c_nodes[b];
+        counters[uint64_t(bi[b]) * 4 + 1] = c_leaf[b];
+        counters[uint64_t(bi[b]) * 4 + 2] = c_mono[b];
+        counters[uint64_t(bi[b]) * 4 + 3] = c_body[b];
+      }
     }
   }
 }
@@ -738,27 +773,36 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   if (s->count == 0) return NBODY_OK;
   const T th  = static_cast<T>(theta);
   const T th2 = th * th;  // src/bvh.h:252, in T
-  const uint32_t blocks = (s->count + 63) / 64;
   auto* node = static_cast<const tree_rec<T>*>(t->node);
-  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured crossover on
-  // 256 CUs: f64 6.08 (sweep) vs 6.38 ms (per-lane) at 400k and 5.16 vs 4.72 ms at 300k; f32 4.79 vs 4.27 ms at 400k.
-  const uint32_t crossover = sizeof(T) == 8 ? 350000u : 600000u;
-  const bool wave = t->traversal == 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
+  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured on 256 CUs (f64,
+  // sweep / per-lane): 9.55 / 20.2 ms at 10^6, 5.93 / 8.40 at 5*10^5, 4.13 / 4.58 at 3*10^5, 4.26 / 2.63 at 2*10^5, 2.84 / 1.17 at 10^5;
+  // f32 7.79 / 12.6 ms at 10^6, 4.02 / 3.94 at 4*10^5.
+  const uint32_t crossover = sizeof(T) == 8 ? 280000u : 400000u;
+  const bool wave = t->traversal >= 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;
   }
-#define NB_LAUNCH(KERN, CNT)                                                                                                 \
-  hipLaunchKernelGGL((KERN<T, D, CNT>), dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a),                          \
-                     static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, s->count, th2, t->nlevels, t->counters)
-  if (wave) {
-    if (t->counters_on) NB_LAUNCH(bvh_force_wave_kernel, true);
-    else NB_LAUNCH(bvh_force_wave_kernel, false);
+  // Bodies per lane of the sweep: 1.  With 2 (128 bodies per wave: half the waves, the scalar half of every step shared)
+  // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
+  // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
+  const int bpl            = t->traversal == 4 ? 2 : 1;
+  const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
+  const uint32_t blocks    = (s->count + per_block - 1) / per_block;
+#define NB_ARGS                                                                                                   \
+  dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, \
+   s->count, th2, t->nlevels, t->counters
+  if (wave && bpl == 2) {
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS);
+  } else if (wave) {
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS);
   } else {
-    if (t->counters_on) NB_LAUNCH(bvh_force_kernel, true);
-    else NB_LAUNCH(bvh_force_kernel, false);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
   }
-#undef NB_LAUNCH
+#undef NB_ARGS
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -849,7 +893,7 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
 
 extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
-  NB_ARG(mode >= 0 && mode <= 2, "traversal mode must be 0 (auto), 1 (per-lane) or 2 (wave-cooperative), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 4, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (wave-cooperative with 1 / 2 bodies per lane), got %d", mode);
   t->traversal = mode;
   return NBODY_OK;
 }

@@ -53,6 +53,16 @@ void run_all_pairs(System<T, D>& sys, Device<T, D>& dev, Options o, char const* 
         saver.save_all(sys, dev);
       }
     });
+  } else if (dev.sharded()) {
+    // several devices driven by this one thread: plain asynchronous launches (5 per device and step against >= 80 ms of force)
+    auto one_step = [&] { force(); dev.accelerate_step(); };
+    for (std::size_t step = 0; step < o.warmup_steps; ++step) one_step();
+    dev.sync();
+    t_total = timed([&] {
+      for (std::size_t step = o.warmup_steps; step < o.steps; ++step) one_step();
+      dev.sync();
+    });
+    o.steps -= o.warmup_steps;
   } else {
     // the step is a fixed launch sequence: record it once, replay it (hipGraph)
     nbody_graph* g = dev.record([&] { force(); dev.accelerate_step(); });
@@ -207,7 +217,14 @@ void run_simulation(Options const& o, System<T, D>& sys) {
   if (!quiet) std::cout << "Starting simulation" << std::endl;
   auto t0 = wall_clock::now();
   {
-    Device<T, D> dev(sys);
+    if (o.gpus > 1 && o.algorithm != Algorithm::AllPairs) {
+      std::cerr << "--gpus " << o.gpus << ": bodies shard over GPUs for --algorithm all-pairs only." << std::endl;
+      std::exit(EXIT_FAILURE);
+    }
+    // NBODY_CLI_FORCE_COMM=1: --gpus 1 through the communicator, shard window and exchange (one-GPU boxes)
+    char const* force_comm = std::getenv("NBODY_CLI_FORCE_COMM");
+    bool const exchange    = o.algorithm == Algorithm::AllPairs && force_comm && force_comm[0] == '1';
+    Device<T, D> dev(sys, o.gpus, exchange);
     switch (o.algorithm) {
       case Algorithm::AllPairs: run_all_pairs(sys, dev, o, "all-pairs", false); break;
       case Algorithm::AllPairsCollapsed: run_all_pairs(sys, dev, o, "all-pairs-collapsed", true); break;

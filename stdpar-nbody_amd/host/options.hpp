@@ -26,6 +26,7 @@ struct Options {
   bool csv_detailed        = false;
   bool csv_total           = false;
   std::optional<std::string> load_input;
+  int gpus = 1;  // not in the reference: --gpus N shards the bodies of --algorithm all-pairs over N devices of this node
 };
 
 namespace detail {
@@ -40,6 +41,7 @@ inline constexpr char const* kHelp =
  "--print-state\t\tPrint the initial and final state of the simulation\n"
  "--print-info\t\tPrint info every timestep\n"
  "--save pos|energy|all|none(default) \t\tSelects what data to save every timestep\n"
+ "--gpus N\t\tShard the bodies over N GPUs of this node (all-pairs only; RCCL all-gather of positions per step)\n"
  "--help\t\tDisplay this help message and quit\n";
 
 [[noreturn]] inline void reject(char const* what, std::string const& got, char const* choices) {
@@ -85,6 +87,12 @@ inline Options parse_options(std::vector<std::string> const& argv) {
         o.load_input = value();
         o.workload   = Workload::Load;
       } else detail::reject("workload", w, "plummer, galaxy, uniform (default)");
+    } else if (f == "--gpus") {
+      o.gpus = std::stoi(value());
+      if (o.gpus < 1) {
+        std::cerr << "--gpus needs a positive device count." << std::endl;
+        std::exit(EXIT_FAILURE);
+      }
     } else if (f == "--print-state") {
       o.print_state = true;
     } else if (f == "--print-info") {

@@ -207,3 +207,36 @@ def test_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tree size" in r.stdout and "root mass" in r.stdout
+
+
+def cli_env(dim, args, env_extra, cwd=None):
+    exe = os.path.join(ROOT, "stdpar-nbody_amd", "bin", f"nbody_hip_d{dim}")
+    env = dict(os.environ)
+    env.update(env_extra)
+    return subprocess.run([exe] + [str(a) for a in args], cwd=cwd, env=env, capture_output=True, text=True, timeout=600)
+
+
+def test_gpus_flag_multi_device_path_on_one_gpu():
+    """--gpus N (not in the reference): one context per device, the ABI's shard per context, nbody_comm_create_all and an
+    nbody_allgather_positions per step.  On the one-GPU box the whole path runs with N = 1 (NBODY_CLI_FORCE_COMM=1) and
+    must print exactly what the plain single-device run prints, in the default and in the --csv-detailed mode with saved
+    frames; asking for more devices than are visible, or for a non-sharding algorithm, fails with a message."""
+    args = ["-n", 3000, "-s", 12, "--precision", "double", "--algorithm", "all-pairs", "--workload", "galaxy", "--print-state"]
+    plain = cli(3, args)
+    forced = cli_env(3, args + ["--gpus", 1], {"NBODY_CLI_FORCE_COMM": "1"})
+    assert plain.returncode == 0 and forced.returncode == 0, forced.stderr
+    strip = lambda out: re.sub(r"Total time: .*", "", out)
+    assert strip(plain.stdout) == strip(forced.stdout)
+    with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
+        a2 = ["-n", 500, "-s", 4, "--precision", "float", "--algorithm", "all-pairs", "--csv-detailed", "--save", "pos"]
+        r1, r2 = cli(2, a2, cwd=d1), cli_env(2, a2 + ["--gpus", 1], {"NBODY_CLI_FORCE_COMM": "1"}, cwd=d2)
+        assert r1.returncode == 0 and r2.returncode == 0, r2.stderr
+        assert open(os.path.join(d1, "positions.bin"), "rb").read() == open(os.path.join(d2, "positions.bin"), "rb").read()
+    import torch
+    too_many = torch.cuda.device_count() + 1
+    r = cli(3, ["-n", 1000, "--algorithm", "all-pairs", "--gpus", too_many])
+    assert r.returncode != 0 and "HIP devices visible" in r.stderr
+    r = cli(3, ["-n", 1000, "--algorithm", "bvh", "--gpus", 2])
+    assert r.returncode != 0 and "all-pairs only" in r.stderr
+    r = cli_env(3, ["-n", 1000, "-s", 2, "--algorithm", "all-pairs", "--gpus", 1, "--save", "energy", "--csv-detailed"], {"NBODY_CLI_FORCE_COMM": "1"})
+    assert r.returncode != 0 and "one GPU only" in r.stderr

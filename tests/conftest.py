@@ -56,6 +56,20 @@ def golden_print_state():
 
 
 @pytest.fixture(scope="session")
+def golden_print_state_n4096():
+    """The reference's final `--print-state` rows at n = 4096 (tests/golden/generate_golden_n4096.py), SURVEY §8(c)."""
+    import gzip
+    with gzip.open(os.path.join(GOLDEN, "print_state_n4096.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def float_tolerance():
+    """Float tolerances measured on two builds of the reference (tests/golden/calibrate_float_tolerance.py)."""
+    return json.load(open(os.path.join(GOLDEN, "float_tolerance.json")))
+
+
+@pytest.fixture(scope="session")
 def golden_hilbert():
     return json.load(open(os.path.join(GOLDEN, "hilbert.json")))
 

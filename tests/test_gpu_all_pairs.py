@@ -7,9 +7,13 @@ Tolerances (stated once, used everywhere below):
     summation order: the reference sums j ascending in one chain, the kernel in 4 wave-partials).
     Two legitimate builds of the reference (-O2 vs -Ofast) differ by 3.6e-15 after one step.
   * double trajectories vs reference frames: rel 1e-11 of the position scale after <= 20 steps.
-  * float forces: 2e-5 * max|a_ref|; float trajectories: 2e-3 relative (the reference itself is not
-    reproducible across its own builds in float).
+  * float forces (one pass): 2e-5 * max|a_ref|.  Float trajectories and forces after several steps: the reference is
+    not reproducible across its own builds in float, so the tolerance is MEASURED on it —
+    tests/golden/calibrate_float_tolerance.py builds the reference -O2 and -Ofast, runs config 1 and smaller cases and
+    records their spread; tests/golden/float_tolerance.json holds 4x that spread, imported below.
 """
+import json
+import os
 import numpy as np
 import pytest
 
@@ -17,8 +21,9 @@ from conftest import DT
 
 pytestmark = pytest.mark.gpu
 
+FLOAT_TOL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "float_tolerance.json")))
 FORCE_TOL = {0: 2e-5, 1: 1e-12}
-TRAJ_TOL = {0: 2e-3, 1: 1e-11}
+TRAJ_TOL = {0: FLOAT_TOL["float_trajectory_rel_small_n"], 1: 1e-11}
 
 
 def maxrel(a, b):
@@ -197,17 +202,38 @@ def test_print_state_text_double_exact(nb, oracle, golden_print_state):
     assert ran >= 12
 
 
+def test_print_state_text_double_exact_n4096(nb, oracle, golden_print_state_n4096):
+    """double `--print-state` identity "for N <= 4096, theta = 0 and all-pairs" — the reference's own printed
+    final rows at n = 4096 (tests/golden/generate_golden_n4096.py), all-pairs and bvh theta = 0, row order included."""
+    for name, case in golden_print_state_n4096.items():
+        hs = nb.build_model(1, case["dim"], case["workload"], case["n"])
+        dev = nb.DeviceSystem.from_host(hs)
+        nb.run(dev, case["algorithm"], nb.executed_steps(case["steps"], False), case["theta"] if case["theta"] is not None else 0.5)
+        out = dev.download()
+        s = oracle.State(1, case["dim"], hs.n)
+        for k in ("m", "x", "v", "a", "ao"):
+            getattr(s, k)[:] = getattr(out, k)
+        rows = oracle.format_state_rows(s)
+        diff = [i for i, (r, g) in enumerate(zip(rows, case["final"])) if r != g]
+        assert len(rows) == len(case["final"]) and not diff, f"{name}: {len(diff)} rows differ, first: {rows[diff[0]]} vs {case['final'][diff[0]]}"
+        dev.close()
+
+
 def test_config1_2d_float_n10000(nb, oracle):
-    """BASELINE config[0]: all-pairs 2D float -n 10000 -s 5 (=> 10 steps). Float tolerance on the trajectory."""
+    """BASELINE config[0]: all-pairs 2D float -n 10000 -s 5 (=> 10 steps).  Close encounters amplify the last float bit, so
+    after 10 steps neither positions nor forces are comparable body by body at rounding level — not even between the
+    reference's own -O2 and -Ofast builds.  The assertions use that measured spread (x4): positions, the worst force and
+    the 99th percentile of the per-body force deviation; plus one fresh force pass at the one-pass tolerance."""
     ref = oracle.build_model(0, 2, "uniform", 10000)
     dev = nb.DeviceSystem.from_host(nb.build_model(0, 2, "uniform", 10000))
     nsteps = nb.executed_steps(5, False)
     nb.run(dev, "all-pairs", nsteps)
     oracle.run(ref, "all-pairs", nsteps)
     out = dev.download()
-    assert np.abs(out.x - ref.x).max() <= TRAJ_TOL[0] * np.abs(ref.x).max()
-    # forces after 10 chaotic float steps are not comparable body by body (close encounters amplify the last
-    # bit; the reference's own -O2 and -Ofast builds differ likewise, SURVEY §0.4) — check one force pass instead
+    assert np.abs(out.x - ref.x).max() <= FLOAT_TOL["config1_trajectory_rel"] * np.abs(ref.x).max()
+    ferr = np.abs(out.a.astype(np.float64) - ref.a).max(axis=1) / np.abs(ref.a).max()
+    assert ferr.max() <= FLOAT_TOL["config1_force_after_10_steps_max_rel"], ferr.max()
+    assert np.quantile(ferr, 0.99) <= FLOAT_TOL["config1_force_after_10_steps_p99_rel"], np.quantile(ferr, 0.99)
     ref1 = oracle.build_model(0, 2, "uniform", 10000)
     dev1 = nb.DeviceSystem.from_host(nb.build_model(0, 2, "uniform", 10000))
     dev1.all_pairs_force()

@@ -58,6 +58,16 @@ def test_print_state_text_exact(oracle, golden_print_state):
         assert oracle.format_state_rows(s) == case["final"], f"{name}: final state"
 
 
+def test_print_state_text_exact_n4096(oracle, golden_print_state_n4096):
+    """The oracle prints the reference's rows at n = 4096 too (double, all-pairs and bvh theta = 0)."""
+    import hashlib
+    for name, case in golden_print_state_n4096.items():
+        s = oracle.build_model(oracle.F64, case["dim"], case["workload"], case["n"])
+        assert hashlib.md5("\n".join(oracle.format_state_rows(s)).encode()).hexdigest() == case["start_md5"], name
+        oracle.run(s, case["algorithm"], max(case["steps"], 10), case["theta"] if case["theta"] is not None else 0.5)
+        assert oracle.format_state_rows(s) == case["final"], name
+
+
 def test_hilbert_known_answers(oracle, golden_hilbert):
     assert len(golden_hilbert) >= 400
     for dim, c0, c1, c2, h, il in golden_hilbert:

@@ -1,0 +1,25 @@
+#!/bin/bash
+# One GPU-box session that produces everything kept under profiles/<tag>/: the bench line, its rocprofv3 summaries (stamped),
+# the per-config timings, the reference-shaped benchmark logs + scraped tables, and PMC passes of K2 and K9.
+# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r02
+TAG=${1:-r02}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+echo "== bench"; timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 600 $O/bench_n1.json
+echo "== profile bench"; timeout -k 10 500 bash tools/profile_bench.sh $TAG > $O/profile_bench.txt 2>&1; tail -5 $O/profile_bench.txt
+echo "== configs"; timeout -k 10 300 python3 tools/measure_configs.py > $O/configs_all.json 2> $O/configs_all.err; grep -c config $O/configs_all.json
+echo "== K1 sizes"; timeout -k 10 200 python3 tools/time_all_pairs.py 10 > $O/k1_times.json 2> $O/k1_times.err
+echo "== matrix"; timeout -k 10 400 bash tools/benchmark.sh 200 > $O/benchmark.log 2> $O/benchmark.err; python3 tools/scrape_bench_log.py $O/benchmark.log > $O/benchmark.csv; cat $O/benchmark.csv
+echo "== detailed"; timeout -k 10 400 bash tools/benchmark_detailed.sh 1000 100000 > $O/benchmark_detailed.log 2> $O/benchmark_detailed.err; python3 tools/scrape_bench_log.py $O/benchmark_detailed.log > $O/benchmark_detailed.csv; cat $O/benchmark_detailed.csv
+echo "== PMC K2 / K9"
+C1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE"
+C2="SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
+PREC=float WL=uniform TAG=pmc_k2 bash tools/pmc_kernel.sh all_pairs_collapsed_kernel all-pairs-collapsed 262144 "$C1" "$C2" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_k2_config3.txt 2>&1
+TAG=pmc_k9 bash tools/pmc_kernel.sh bvh_force_wave bvh 1000000 "$C1" "$C2" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_k9_config4.txt 2>&1
+cat $O/pmc_k2_config3.txt $O/pmc_k9_config4.txt
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k2 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 262144 -s 12 --precision float --algorithm all-pairs-collapsed --workload uniform --csv-total > $O/trace_k2.txt 2>&1
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k9 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 1000000 -s 12 --precision double --algorithm bvh --workload galaxy --csv-total > $O/trace_k9.txt 2>&1
+find $O/trace_k2 $O/trace_k9 -name "*kernel_stats.csv" | while read f; do echo $f; head -6 $f; done

@@ -18,6 +18,7 @@
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+#include <unistd.h>
 
 #include <mutex>
 #include <vector>
@@ -84,6 +85,25 @@ int rccl_fail(ncclResult_t r, const char* what) {
   return NBODY_ERR_HIP;
 }
 
+// RCCL prints a version banner on stdout when the first communicator of a process is created.  stdout belongs to the
+// caller (the CLI prints its CSV rows and --print-state text there): while a communicator is being created, fd 1 is
+// pointed at stderr.
+struct stdout_to_stderr {
+  int saved = -1;
+  stdout_to_stderr() {
+    fflush(stdout);
+    saved = dup(1);
+    if (saved >= 0) (void)dup2(2, 1);
+  }
+  ~stdout_to_stderr() {
+    if (saved >= 0) {
+      fflush(stdout);
+      (void)dup2(saved, 1);
+      close(saved);
+    }
+  }
+};
+
 #define NB_RCCL(call)                                        \
   do {                                                       \
     ncclResult_t r_ = (call);                                \
@@ -119,11 +139,14 @@ extern "C" int nbody_comm_create(nbody_comm** out, int world, int rank, const vo
   int ndev = 0;
   NB_HIP(hipGetDeviceCount(&ndev));
   NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
-  NB_HIP(hipSetDevice(device));
+  device_guard guard(device);
   ncclUniqueId id;
   memcpy(id.internal, unique_id, NCCL_UNIQUE_ID_BYTES);
   ncclComm_t comm = nullptr;
-  NB_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  {
+    stdout_to_stderr quiet;
+    NB_RCCL(g_rccl.CommInitRank(&comm, world, id, rank));
+  }
   auto* c   = new nbody_comm;
   c->comm   = comm;
   c->world  = world;
@@ -147,7 +170,10 @@ extern "C" int nbody_comm_create_all(nbody_comm** out, int ndev, const int* devi
            visible);
   }
   std::vector<ncclComm_t> comms(static_cast<size_t>(ndev), nullptr);
-  NB_RCCL(g_rccl.CommInitAll(comms.data(), ndev, devs.data()));
+  {
+    stdout_to_stderr quiet;
+    NB_RCCL(g_rccl.CommInitAll(comms.data(), ndev, devs.data()));
+  }
   for (int i = 0; i < ndev; ++i) {
     auto* c   = new nbody_comm;
     c->comm   = comms[size_t(i)];
@@ -162,7 +188,7 @@ extern "C" int nbody_comm_create_all(nbody_comm** out, int ndev, const int* devi
 extern "C" void nbody_comm_destroy(nbody_comm* c) {
   if (!c) return;
   if (c->comm && g_rccl.ok) {
-    (void)hipSetDevice(c->device);
+    device_guard guard(c->device);
     (void)g_rccl.CommDestroy(c->comm);
   }
   delete c;

@@ -3,11 +3,10 @@
 # ci/benchmark_detailed emit them (ci/benchmark:44-50: the two-line `name, driver_version` CSV of the GPU query, lscpu's
 # "Model name" and "Core(s) per socket" lines, "hostname:<name>") so that tools/scrape_bench_log.py — like the reference's
 # ci/data.py — can attach them to every result row.  Sourced by tools/benchmark.sh and tools/benchmark_detailed.sh.
-GPU=$(/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 "Marketing Name:.*\(MI\|Instinct\)" | sed 's/.*Marketing Name: *//' | tr -d ',' || true)
-ARCH=$(/opt/rocm/bin/rocminfo 2>/dev/null | grep -m1 -o "gfx[0-9a-z]*" || true)
-DRV=$(cat /sys/module/amdgpu/version 2>/dev/null || /opt/rocm/bin/rocm-smi --showdriverversion 2>/dev/null | grep -m1 -o "[0-9][0-9.]*$" || echo unknown)
+# rocminfo needs /dev/kfd privileges the GPU box's user may lack: ask the HIP runtime through PyTorch (device name, HIP version)
+ID=$(python3 -c "import torch; print(torch.cuda.get_device_name(0).replace(',', ' ') + ', ' + str(torch.version.hip))" 2>/dev/null || echo "AMD Instinct (gfx950), unknown")
 echo "name, driver_version"
-echo "${GPU:-AMD Instinct} (${ARCH:-unknown}), ${DRV:-unknown}"
+echo "$ID"
 lscpu | grep "Model name"
 lscpu | grep "Core(s) per socket"
 echo "hostname:$(hostname)"

@@ -346,7 +346,7 @@ void ap_scratch_release(hipStream_t st) {
 // What fixes the ROUNDING ORDER of a target's sum is derived from sz alone — never from first/count — so every shard
 // of a multi-GPU run sums exactly as the single-GPU run does:
 //   * split  (JS): the 512-record tile is cut into JS slices, one per wave of a target group; 8 slices (512-thread
-//     blocks, scalar-stream form only) once sz >= 65 536, else 4;
+//     blocks, scalar-stream form only) once sz >= 2048, else 4;
 //   * chunks (Y):  the tile sequence is cut into Y runs, one per grid.y, each run summed by its own block and the Y
 //     sums combined in run order by a second kernel.  Equal-sized blocks that start together finish together, so a
 //     launch costs ceil(blocks / resident slots) block times: 1563 blocks on 1024 slots (N = 10^5) ran at 31 % of peak
@@ -359,15 +359,19 @@ struct k1_plan {
   uint32_t chunks = 1, tiles_per_chunk = 0;
 };
 
-static int auto_split(uint32_t sz) { return sz >= 65536u ? 8 : 4; }
+static int auto_split(uint32_t sz) { return sz >= 2048u ? 8 : 4; }
 
+// Chunks from sz alone: min(16, tiles, 2^22 / sz rounded up to a power of two) — 4 at N = 2^20 (whole system: 32 768
+// blocks; a 1/8 shard: 4096), 16 from 262 144 down to 8192 bodies, one tile per chunk below that.  Measured
+// (profiles/r02/k1_chunks_tuning.txt, gpurun_out/r02/tune_small.txt; f64, ms per pass, chunks 1 / this rule):
+// N = 4096: 0.070 / 0.023, 10^4: 0.166 / 0.083, 3*10^4: 0.66 / 0.57, 65 536: 2.64 / 2.50, 10^5: 7.45 / 5.81,
+// 2^20: 637 / 635, its 1/8 shard: 83.8 / 80.6.  More chunks than this change nothing (N = 10^5: 64 chunks 5.87 ms).
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk) {
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
   uint32_t y = 1;
-  // 2^22 / sz runs (4 at N = 2^20, 16 at 262 144, 64 -> capped below at 65 536), each at least 8 tiles (4096 sources) long
-  while (y < 64 && uint64_t(y) * 2 * sz <= (1ull << 22) && ntiles / (y * 2) >= 8) y *= 2;
-  uint32_t tpc = (ntiles + y - 1) / y;
-  if (tpc == 0) tpc = 1;
+  while (y < 16 && uint64_t(y) * sz < (1ull << 22)) y *= 2;
+  if (y > ntiles) y = ntiles ? ntiles : 1;
+  uint32_t tpc = ntiles ? (ntiles + y - 1) / y : 1;
   *tiles_per_chunk = tpc;
   *chunks          = ntiles ? (ntiles + tpc - 1) / tpc : 1;
 }
@@ -378,9 +382,10 @@ static int plan_all_pairs(const nbody_state* s, k1_plan* out) {
   k1_plan p;
   p.js = cfg.split ? cfg.split : auto_split(s->sz);
   p.r  = cfg.tpt;
-  // Source path (bitwise identical results, so the choice may depend on the shard size).  The scalar stream pays an SMEM
-  // round trip per 64-byte batch, which needs several waves per SIMD to hide: measured f64, split 4, lds / sgpr:
-  // 0.16 / 0.34 ms at N = 10^4, 0.78 / 0.98 ms at 3*10^4, 3.20 / 3.11 ms at 65 536, 8.62 / 8.32 ms at 10^5, 746 / 722 ms at 2^20.
+  // Source path (bitwise identical results at equal split and chunks).  The scalar stream pays an SMEM round trip per
+  // 64-byte batch, which needs several waves per SIMD to hide — the source chunks supply them at every size (N = 10^4,
+  // f64: LDS tiles 0.19 ms, scalar stream unchunked 0.17-0.33 ms, with 16 chunks 0.083 ms), so the automatic choice is the
+  // scalar stream wherever the 8-slice split applies; the LDS-tile form remains for tiny systems and on request.
   const uint64_t waves_r1 = (uint64_t(s->count) + 63) / 64 * uint64_t(p.js);
   p.scalar                = p.js == 8 || cfg.path == 2 || (cfg.path == 0 && waves_r1 >= 4096);
   if (p.js == 8 && cfg.path == 1) {

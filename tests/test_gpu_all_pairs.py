@@ -120,7 +120,7 @@ def test_source_paths_are_bitwise_identical(nb, dtype, dim):
     arithmetic in the same order, for every (split, targets-per-lane) configuration and for shard windows."""
     n = 5000 + 37 * dim
     try:
-        for split, tpt in ((0, 0), (1, 1), (2, 2), (4, 1), (4, 2), (1, 2)):  # n < 65536: auto split is 4 in both forms
+        for split, tpt in ((1, 1), (2, 2), (4, 1), (4, 2), (1, 2)):  # explicit splits: one source chunk in both forms
             res = []
             for path in (1, 2):
                 nb.configure_all_pairs(split, tpt, source_path=path)
@@ -132,6 +132,19 @@ def test_source_paths_are_bitwise_identical(nb, dtype, dim):
                 res.append(full)
                 dev.close()
             assert np.array_equal(res[0], res[1]), (split, tpt)
+        # the automatic launch (8 slices, source chunks over grid.y): shard windows and both targets-per-lane settings agree
+        nb.configure_all_pairs(0, 0, source_path=0)
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, "galaxy", n))
+        assert "chunks=10" in nb.describe_all_pairs(dev.state()) and "JS=8" in nb.describe_all_pairs(dev.state())
+        dev.all_pairs_force()
+        full = dev.download().a.copy()
+        dev.all_pairs_force(1000, 2049)
+        assert np.array_equal(dev.download().a, full)
+        for tpt in (1, 2):
+            nb.configure_all_pairs(0, tpt)
+            dev.all_pairs_force()
+            assert np.array_equal(dev.download().a, full), tpt
+        dev.close()
     finally:
         nb.configure_all_pairs(0, 0, source_path=0)
 

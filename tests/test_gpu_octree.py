@@ -242,6 +242,54 @@ def test_octree_errors(nb):
         d2.octree.compute_force(d2.state(), 0.5, d2.stream)
 
 
+def test_octree_run_paths_raise_on_device_flags(nb):
+    """A flagged build drops mass (cells still holding >= 2 bodies stay empty leaves): the step loops must not integrate on.
+    nb.run() reads the sticky device-side flag every OCTREE_CHECK_EVERY steps and after the last step; ShardedOctree does
+    the same (check()); the CLI checks after its warm-up steps and at the end (non-zero exit, message on stderr)."""
+    import os
+    import subprocess
+    import tempfile
+    import torch
+    from conftest import ROOT
+    hs = nb.HostSystem(1, 3, 40)
+    rng = np.random.default_rng(2)
+    hs.m[:] = 1
+    hs.x[:] = rng.uniform(-1, 1, hs.x.shape)
+    hs.x[7] = hs.x[3]  # two coincident bodies
+    hs.c, hs.dt = 1e-6, 1e-3
+    dev = nb.DeviceSystem.from_host(hs)
+    with pytest.raises(nb.NbodyError, match="node pool exhausted|depth limit"):
+        nb.run(dev, "octree", 3, 0.5)
+    saved = nb.OCTREE_CHECK_EVERY
+    try:
+        nb.OCTREE_CHECK_EVERY = 2   # the periodic check fires inside the loop, before the final one
+        dev2 = nb.DeviceSystem.from_host(hs)
+        calls = []
+        orig = dev2.octree.info
+        dev2.octree.info = lambda stream=None: (calls.append(1), orig(stream))[1]
+        with pytest.raises(nb.NbodyError):
+            nb.run(dev2, "octree", 5, 0.5)
+        assert len(calls) == 1   # raised at step 2, not at the end
+    finally:
+        nb.OCTREE_CHECK_EVERY = saved
+    sim = nb.parallel.ShardedOctree(hs, 0, 1, theta=0.5, torch_device=torch.device("cuda", 0))
+    sim.step()
+    with pytest.raises(nb.NbodyError, match="node pool exhausted|depth limit"):
+        sim.check()
+    # the same system through the CLI (--workload load): f32 file format of src/saving.h:25-68
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "bad.bin")
+        with open(path, "wb") as f:
+            f.write(np.array([hs.n, 3], np.uint32).tobytes() + np.array([hs.dt, hs.c], np.float32).tobytes())
+            rec = np.zeros((hs.n, 7), np.float32)
+            rec[:, 0], rec[:, 1:4] = hs.m, hs.x
+            f.write(rec.tobytes())
+        exe = os.path.join(ROOT, "stdpar-nbody_amd", "bin", "nbody_hip_d3")
+        r = subprocess.run([exe, "--workload", "load", path, "--algorithm", "octree", "--precision", "double", "-s", "12"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode != 0 and ("node pool exhausted" in r.stderr or "depth limit" in r.stderr), r.stderr
+
+
 def test_octree_full_size(nb, oracle):
     """N = 1e6 galaxy, theta = 0.5 (the reference's tree benchmark size): whole force phase vs the oracle."""
     n = 1000000

@@ -268,11 +268,31 @@ def main():
 
     # the data-path collective is the library's own (nbody_allgather_positions, RCCL behind the C ABI); torch.distributed
     # is the launcher's side: it carries the RCCL unique id to the ranks, the barriers and the max-over-ranks of the time
-    comm = None
+    comm, comm_note = None, None
     if use_dist:
-        box = [nb.Comm.unique_id() if rank == 0 else None]
+        # Every rank must end up on the same exchange: if the communicator cannot be created on ANY rank (RCCL not loadable
+        # through dlopen, a version clash with the copy PyTorch mapped), all ranks use the torch.distributed form of the
+        # same all-gather (still RCCL) and the line says so.
+        ok, err = 1, ""
+        try:
+            box = [nb.Comm.unique_id() if rank == 0 else None]
+        except Exception as ex:
+            box, ok, err = [None], 0, str(ex)
         dist.broadcast_object_list(box, src=0)
-        comm = nb.Comm(world, rank, box[0], local_rank)
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                comm = nb.Comm(world, rank, box[0], local_rank)
+            except Exception as ex:
+                ok, err = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if comm is not None:
+                comm.close()
+            comm, comm_note = None, "nbody_comm unavailable on some rank (%s): torch.distributed all_gather instead" % (err or "another rank")
+            print("bench.py: " + comm_note, file=sys.stderr)
 
     # synthetic galaxy init with the product's host generator (host/models.hpp == src/models.h:112-136)
     hs = nb.build_model(nb.F64, 3, "galaxy", args.n)
@@ -280,9 +300,21 @@ def main():
     sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev, force_exchange=use_dist, comm=comm)
     kernel_desc = nb.describe_all_pairs(sim.state())
 
-    for _ in range(args.warmup):
+    for _ in range(max(args.warmup, 1) if use_dist else args.warmup):
         sim.step()
+    exchange_check = None
     if use_dist:
+        # after a step every rank must hold the same positions: two checksums of the full x, compared across the ranks
+        # (a rank whose exchange did not deliver would keep stale rows, and the number below would mean nothing)
+        wts = torch.arange(1, sim.x.numel() + 1, dtype=torch.float64, device=dev).reshape(sim.x.shape)
+        sums = torch.stack([sim.x.sum(), (sim.x * wts).sum()])
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit(f"rank {rank}: positions differ between ranks after the exchange (checksums {sums.tolist()})")
+        exchange_check = "full x identical on all %d rank(s) after the warm-up exchange (2 checksums, min == max over ranks)" % world
+        del wts
         dist.barrier()
     torch.cuda.synchronize()
     telemetry = Telemetry(local_rank) if rank == 0 else None
@@ -329,7 +361,9 @@ def main():
                        else "single GPU", "split": sim.describe()},
             "pct_fp64_peak": 100.0 * whole_job_tflops / (FP64_VECTOR_PEAK_TFLOPS * world),
             "rccl_world": ({"world": dist.get_world_size(), "backend": dist.get_backend(),
-                            "data_path": "nbody_comm (ncclCommInitRank) world %d, RCCL %d" % (comm.world, nb.Comm.rccl_version())}
+                            "data_path": ("nbody_comm (ncclCommInitRank) world %d, RCCL %d" % (comm.world, nb.Comm.rccl_version())
+                                          if comm is not None else comm_note),
+                            "exchange_check": exchange_check}
                            if use_dist else None),
             "shards": [e - f for f, e in sim.shards],
             "allgather": {"sent_bytes_per_rank_per_step": sim.count * row, "gathered_bytes_per_step": n * row,

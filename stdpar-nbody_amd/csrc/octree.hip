@@ -646,19 +646,54 @@ __device__ __forceinline__ bool ot_accept(bool need, T side, const T (&dj)[D], T
   return take;
 }
 
-// a += mj * (xj - x) / dx^3, dx = sqrt(d2) + eps (src/octree.h:240-241), for the lanes in `on`; tolerance parity: sqrt from
-// the polished seed (3/8 * 2^-48 relative), 1/dx^3 from a polished reciprocal.  dj = xj - x, d2f = ot_dist2_fused(dj),
-// y0 = rsq(d2f).  The body's own leaf and empty leaves add exactly 0 (dj == 0 or mj == 0): dx^3 >= eps^3 keeps the
-// weight finite.
+// a += mj * (xj - x) / dx^3, dx = sqrt(d2) + eps (src/octree.h:240-241), for the lanes in `on` (tolerance parity).
+// dj = xj - x, d2f = ot_dist2_fused(dj), y0 = rsq(d2f) — the seed the opening test already paid for.
+//   far  (d2 >= 2^-46 in f64, 2^-18 in f32): no square root, no reciprocal.  With s = sqrt(d2):
+//        1/(s + eps)^3 = s^-3 * (1 + eps/s)^-3 = s^-3 * (1 - 3 eps/s + 6 (eps/s)^2 - ...), and eps/s <= 2^-29 (2^-14) there, so
+//        the dropped 6 (eps/s)^2 is below half an ulp.  f64: s^-3 from the 2^-24 seed by the third-order step on the cube
+//        K1 uses (pair_math<double>::weight_far), both corrections in one FMA: w = (mj*y^3)(1 + e(3/2 + 15/8 e) - 3 eps y):
+//        8 full-rate ops.  f32: the 1-ulp seed cubed, 5 ops.  (Round 1: polished sqrt, cube, polished v_rcp: 12 ops + a
+//        quarter-rate transcendental.)
+//   near (anything closer — the body's own leaf, coincident or very close bodies; found with one compare on the high word
+//        and one wave-uniform branch): the reference's expression from a polished sqrt and reciprocal, kept per lane.
+// The body's own leaf and empty leaves add exactly 0 (dj == 0 or mj == 0): dx^3 >= eps^3 keeps the near weight finite.
+template <typename T>
+struct ot_near {
+  static constexpr uint32_t bits = sizeof(T) == 8 ? 0x3D100000u : 0x36800000u;  // high word of 2^-46 / bits of 2^-18
+  __device__ static __forceinline__ uint32_t of(T d2) {
+    if constexpr (sizeof(T) == 8) return uint32_t(__builtin_bit_cast(unsigned long long, d2) >> 32);
+    else return __builtin_bit_cast(uint32_t, d2);
+  }
+};
+
 template <typename T, int D>
-__device__ __forceinline__ void ot_accumulate(bool on, T (&acc)[D], const T (&dj)[D], T mj, T d2f, T y0) {
+__device__ __forceinline__ void ot_accumulate(bool on, uint64_t on_mask, T (&acc)[D], const T (&dj)[D], T mj, T d2f, T y0,
+                                              const pair_consts<T>& pc) {
+  T w;
+  if constexpr (sizeof(T) == 8) {
+    const T a  = y0 * y0;
+    const T e  = __builtin_elementwise_fma(-d2f, a, T(1));
+    const T y3 = a * y0;
+    const T p  = __builtin_elementwise_fma(e, pc.k1875, pc.k15);
+    const T g  = __builtin_elementwise_fma(p, e, -(T(3) * ot_consts<T>::eps) * y0);
+    const T my = mj * y3;
+    w          = __builtin_elementwise_fma(my, g, my);
+  } else {
+    (void)pc;
+    const T my = mj * ((y0 * y0) * y0);
+    w          = __builtin_elementwise_fma(my, -(T(3) * ot_consts<T>::eps) * y0, my);
+  }
+  const bool close = ot_near<T>::of(d2f) < ot_near<T>::bits;
+  if (__builtin_expect((__builtin_amdgcn_ballot_w64(close) & on_mask) != 0ull, 0)) {
 #pragma clang fp contract(off)
-  const T t  = d2f * y0;
-  const T e  = __builtin_elementwise_fma(-t, y0, T(1));
-  const T sq = __builtin_elementwise_fma(T(0.5) * t, e, t);
-  const T dx = sq + ot_consts<T>::eps;
-  T w        = mj * ot_recip((dx * dx) * dx);
-  w          = on ? w : T(0);
+    const T t  = d2f * y0;
+    const T e  = __builtin_elementwise_fma(-t, y0, T(1));
+    const T sq = __builtin_elementwise_fma(T(0.5) * t, e, t);
+    const T dx = sq + ot_consts<T>::eps;
+    const T wn = mj * ot_recip((dx * dx) * dx);
+    w          = close ? wn : w;
+  }
+  w = on ? w : T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, dj[k], acc[k]);
 }
@@ -749,6 +784,7 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   const bool valid    = t < nlist;
   const uint32_t body = valid ? list[t] : first;
   const ot_theta<T> th(theta);
+  const pair_consts<T> pc;
   const T root_side = root[D];
   T xi[D], acc[D];
 #pragma unroll
@@ -768,7 +804,11 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
     const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;  // kOtBody or kOtEmpty
     const bool take = leaf || ot_accept<T, D>(!leaf, root_side, di, y0, th);
-    if (take) ot_accumulate<T, D>(cc == 0, acc, di, nd.m, d2f, y0);
+    {
+      const bool on0 = take && cc == 0;  // the root is examined by every lane of the group; lane 0 keeps the result
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(on0);
+      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, acc, di, nd.m, d2f, y0, pc);
+    }
     if (COUNT && cc == 0) {
       c_nodes = 1;
       c_terms = take;
@@ -790,7 +830,8 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
       ++c_nodes;
       c_terms += take;
     }
-    if (__ballot(take) != 0ull) ot_accumulate<T, D>(take, acc, di, nd.m, d2f, y0);
+    const uint64_t take_mask = __builtin_amdgcn_ballot_w64(take);
+    if (take_mask != 0ull) ot_accumulate<T, D>(take, take_mask, acc, di, nd.m, d2f, y0, pc);
     const uint32_t open_mask = uint32_t((__ballot(!take) >> (g * NCH)) & ((1ull << NCH) - 1ull));
     if (sp + uint32_t(__builtin_popcount(open_mask)) > DEPTH) {  // only below the key depth can a walk hold this many
       if (cc == 0) atomicOr(flags, kFlagStack);                  // pending nodes; reported by nbody_octree_info

@@ -22,4 +22,6 @@ cat $O/pmc_k2_config3.txt $O/pmc_k9_config4.txt
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k2 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 262144 -s 12 --precision float --algorithm all-pairs-collapsed --workload uniform --csv-total > $O/trace_k2.txt 2>&1
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k9 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 1000000 -s 12 --precision double --algorithm bvh --workload galaxy --csv-total > $O/trace_k9.txt 2>&1
-find $O/trace_k2 $O/trace_k9 -name "*kernel_stats.csv" | while read f; do echo $f; head -6 $f; done
+timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_energy -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 262144 -s 3 --precision double --algorithm all-pairs --workload galaxy --csv-detailed --save energy > $O/trace_energy.txt 2>&1
+cd $R; timeout -k 10 120 python3 tools/time_energy.py > $O/energy_times.txt 2>&1; timeout -k 10 120 python3 tools/time_octree.py > $O/octree_times.txt 2>&1; cd /tmp
+find $O/trace_k2 $O/trace_k9 $O/trace_energy -name "*kernel_stats.csv" | while read f; do echo $f; head -6 $f; done

@@ -4,7 +4,7 @@
 # "Model name" and "Core(s) per socket" lines, "hostname:<name>") so that tools/scrape_bench_log.py — like the reference's
 # ci/data.py — can attach them to every result row.  Sourced by tools/benchmark.sh and tools/benchmark_detailed.sh.
 # rocminfo needs /dev/kfd privileges the GPU box's user may lack: ask the HIP runtime through PyTorch (device name, HIP version)
-ID=$(python3 -c "import torch; print(torch.cuda.get_device_name(0).replace(',', ' ') + ', ' + str(torch.version.hip))" 2>/dev/null || echo "AMD Instinct (gfx950), unknown")
+ID=$(python3 -c "import torch; p = torch.cuda.get_device_properties(0); print(p.name.replace(chr(44), chr(32)) + chr(32) + chr(40) + p.gcnArchName.split(chr(58))[0] + chr(41) + chr(44) + chr(32) + str(torch.version.hip))" 2>/dev/null || echo "AMD Instinct (gfx950), unknown")
 echo "name, driver_version"
 echo "$ID"
 lscpu | grep "Model name"

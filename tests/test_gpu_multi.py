@@ -45,7 +45,7 @@ def test_bench_self_launch_forced_dist_matches_plain_run():
         assert plain[k] == forced[k], k
     assert plain["roofline"]["kernel"] == forced["roofline"]["kernel"]
     assert plain["config"]["n_bodies"] == forced["config"]["n_bodies"] == 1 << 17
-    assert abs(forced["value"] / plain["value"] - 1.0) < 0.15, (forced["value"], plain["value"])
+    assert abs(forced["value"] / plain["value"] - 1.0) < 0.3, (forced["value"], plain["value"])
     assert 0.2 < plain["roofline"]["frac"] < 0.7
 
 

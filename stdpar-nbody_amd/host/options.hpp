@@ -26,7 +26,9 @@ struct Options {
   bool csv_detailed        = false;
   bool csv_total           = false;
   std::optional<std::string> load_input;
-  int gpus = 1;  // not in the reference: --gpus N shards the bodies of --algorithm all-pairs over N devices of this node
+  // not in the reference (and therefore not in the --help text, which stays the reference's word for word): --gpus N shards
+  // the bodies of --algorithm all-pairs over N devices of this node, one RCCL all-gather of positions per step
+  int gpus = 1;
 };
 
 namespace detail {
@@ -41,7 +43,6 @@ inline constexpr char const* kHelp =
  "--print-state\t\tPrint the initial and final state of the simulation\n"
  "--print-info\t\tPrint info every timestep\n"
  "--save pos|energy|all|none(default) \t\tSelects what data to save every timestep\n"
- "--gpus N\t\tShard the bodies over N GPUs of this node (all-pairs only; RCCL all-gather of positions per step)\n"
  "--help\t\tDisplay this help message and quit\n";
 
 [[noreturn]] inline void reject(char const* what, std::string const& got, char const* choices) {

@@ -55,8 +55,6 @@ struct nbody_bvh {
   void* node      = nullptr;
   void* box       = nullptr;
   uint32_t* counters = nullptr;
-  uint32_t* cost  = nullptr;  // sweep length of every 64-body group in the last traversal (K9's launch order)
-  uint32_t* order = nullptr;  // groups of each XCD's range, longest sweep first
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
@@ -430,51 +428,6 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nb
   return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + slot;
 }
 
-// Launch order of the traversal.  A wave's sweep is 3k-14k steps long (config 4: mean 7.4k, p10 5.7k, p90 9.0k), a SIMD slot
-// runs only about two of them per launch, and the hardware hands out blocks in index order: measured wave durations put the
-// makespan of that order at 9.3 ms (the kernel took 9.55) against 6.9 ms for longest-first and 6.5 ms for a perfect packing.
-// Lengths change slowly from step to step, so every traversal records its groups' step counts and the next one starts
-// the long ones first: inside each XCD's contiguous range of groups (the L2 locality of xcd_contiguous_block is kept)
-// the groups are ranked by their last length.  Results do not depend on the order, only the time does.
-constexpr uint32_t kOrderMax = 8192;  // groups per XCD range the one-block rank sort handles (N <= 4.2M bodies)
-__device__ __forceinline__ void xcd_range(uint32_t xcd, uint32_t nblocks, uint32_t* start, uint32_t* len) {
-  const uint32_t q = nblocks / 8u, r = nblocks % 8u;
-  *start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-  *len   = q + (xcd < r ? 1u : 0u);
-}
-
-__global__ __launch_bounds__(1024) void bvh_order_kernel(uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
-                                                          uint32_t nblocks) {
-  __shared__ uint32_t c[kOrderMax];
-  uint32_t start, len;
-  xcd_range(blockIdx.x, nblocks, &start, &len);
-  if (len > kOrderMax) {  // too many groups for one block: keep the natural order
-    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-      order[start + i] = start + i;
-      cost[start + i]  = 0;
-    }
-    return;
-  }
-  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-    c[i]            = cost[start + i];
-    cost[start + i] = 0;  // consumed: the traversal that follows records the new lengths (the per-lane form with atomicMax)
-  }
-  __syncthreads();
-  for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-    const uint32_t ci = c[i];
-    uint32_t rank     = 0;
-    for (uint32_t j = 0; j < len; ++j) rank += (c[j] > ci) || (c[j] == ci && j < i);  // longest first, ties by index
-    order[start + rank] = start + i;
-  }
-}
-
-// group of this block: the XCD it runs on (block index mod 8) owns one contiguous range of groups, taken longest first
-__device__ __forceinline__ uint32_t ordered_group(const uint32_t* __restrict__ order, uint32_t b, uint32_t nblocks) {
-  uint32_t start, len;
-  xcd_range(b % 8u, nblocks, &start, &len);
-  return order[start + b / 8u];
-}
-
 // Per-lane form: the reference's loop, one independent stackless walk per lane.  With bodies as tree entries every
 // iteration is the same short program — fetch, (test), accumulate if accepted, move — so a lane standing on a body
 // no longer makes the whole wave run a separate two-body path.  Software-pipelined: a step's DECISION (opening
@@ -483,12 +436,9 @@ __device__ __forceinline__ uint32_t ordered_group(const uint32_t* __restrict__ o
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
                                                        T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
-                                                       uint32_t nlevels, uint32_t* __restrict__ counters,
-                                                       const uint32_t* __restrict__ order, uint32_t* __restrict__ cost) {
-  const uint32_t group = ordered_group(order, blockIdx.x, gridDim.x);  // longest walks first (see bvh_order_kernel)
-  const uint32_t local = group * 64 + threadIdx.x;
+                                                       uint32_t nlevels, uint32_t* __restrict__ counters) {
+  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (local >= count) return;
-  uint32_t nsteps = 0;
   const uint32_t i = first + local;
   const pair_consts<T> pc;
   T xs[D], acc[D];
@@ -545,10 +495,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     tree_index = n_index;
     level      = n_level;
     covered    = n_cov;
-    ++nsteps;
   }
-  // the wave ran as long as its longest walk: a relaxed max is enough (cost[] is only a launch-order hint)
-  atomicMax(&cost[group], nsteps);
 #pragma unroll
   for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
   if (COUNT) {
@@ -616,13 +563,10 @@ template <typename T, int D, int BPL, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
-                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ order,
-                                                            uint32_t* __restrict__ cost) {
+                                                            uint32_t* __restrict__ counters) {
   constexpr uint32_t DONE = 0xffffffffu;
   constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
-  const uint32_t group = ordered_group(order, blockIdx.x, gridDim.x);
-  const uint32_t base  = group * (64u * BPL) + threadIdx.x;
-  uint32_t nsteps      = 0;
+  const uint32_t base = xcd_contiguous_block(blockIdx.x, gridDim.x) * (64u * BPL) + threadIdx.x;
   const pair_consts<T> pc;
   T xs[BPL][D], acc[BPL][D];
   uint32_t key[BPL], bi[BPL];
@@ -734,9 +678,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       off                  = (((1u << level) - 1u) + ((cand >> 5) >> shift)) * RB;
     }
     cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR
-    ++nsteps;
   }
-  if (threadIdx.x == 0) cost[group] = nsteps;  // the next traversal's launch order
 #pragma unroll
   for (int b = 0; b < BPL; ++b) {
     if (valid[b]) {
@@ -832,19 +774,17 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th  = static_cast<T>(theta);
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
-  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured on 256 CUs (ms, sweep /
-  // per-lane, both with the longest-first launch order; profiles/r02/k9_modes.txt): f64 8.4 / 21.4 at 10^6, 4.18 / 8.37 at
-  // 5*10^5, 3.14 / 4.39 at 3*10^5, 3.65 / 2.56 at 2*10^5, 2.35 / 1.18 at 10^5; f32 7.0 / 12.8 at 10^6, 2.80 / 3.77 at 4*10^5,
-  // 2.45 / 2.89 at 3*10^5, 2.22 / 1.61 at 2*10^5.
-  const uint32_t crossover = 250000u;
+  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured on 256 CUs (f64,
+  // sweep / per-lane): 9.55 / 20.2 ms at 10^6, 5.93 / 8.40 at 5*10^5, 4.13 / 4.58 at 3*10^5, 4.26 / 2.63 at 2*10^5, 2.84 / 1.17 at 10^5;
+  // f32 7.79 / 12.6 ms at 10^6, 4.02 / 3.94 at 4*10^5.
+  const uint32_t crossover = sizeof(T) == 8 ? 280000u : 400000u;
   const bool wave = t->traversal >= 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;
   }
   // Bodies per lane of the sweep: 1.  With 2 (128 bodies per wave: half the waves, the scalar half of every step shared)
-  // config 4 takes 9.1 ms against 8.3 (12.2 against 9.55 before the launch order) — the union of 128 walks is that much
-  // longer than the union of 64 (f32: 6.9 ms either way).  Traversal
+  // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
   // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
   const int bpl            = t->traversal == 4 ? 2 : 1;
   const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
@@ -852,18 +792,15 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 #define NB_ARGS                                                                                                   \
   dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, \
    s->count, th2, t->nlevels, t->counters
-  // longest walks first (bvh_order_kernel): the order comes from the step counts the previous traversal left in t->cost
-  hipLaunchKernelGGL(bvh_order_kernel, dim3(8), dim3(1024), 0, st, t->cost, t->order, blocks);
-  NB_HIP(hipGetLastError());
   if (wave && bpl == 2) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS, t->order, t->cost);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS, t->order, t->cost);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS);
   } else if (wave) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS, t->order, t->cost);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS, t->order, t->cost);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS);
   } else {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS, t->order, t->cost);
-    else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS, t->order, t->cost);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
+    else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
   }
 #undef NB_ARGS
   NB_HIP(hipGetLastError());
@@ -922,12 +859,6 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
-  {
-    const size_t groups = (size_t(n) + 63) / 64;
-    NB_ALLOC(t->cost, sizeof(uint32_t) * groups);
-    NB_ALLOC(t->order, sizeof(uint32_t) * groups);
-    if (hipError_t e = hipMemset(t->cost, 0, sizeof(uint32_t) * groups); e != hipSuccess) return fail(e, "hipMemset(cost)");
-  }
 #undef NB_ALLOC
   *out = t;
   return NBODY_OK;
@@ -947,8 +878,6 @@ extern "C" void nbody_bvh_destroy(nbody_bvh* t) {
   (void)hipFree(t->node);
   (void)hipFree(t->box);
   (void)hipFree(t->counters);
-  (void)hipFree(t->cost);
-  (void)hipFree(t->order);
   delete t;
 }
 

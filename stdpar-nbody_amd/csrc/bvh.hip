@@ -317,6 +317,7 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
     r.v[D + 1] = node_width<T, D>(b);
   }
   r.v[D + 2]                          = r.v[D + 1] * r.v[D + 1];  // the product the opening test needs, rounded once
+  ba.v[D + 2] = bb.v[D + 2] = T(-1);  // a body entry is always accepted: -1 < theta^2 * d2 holds for every d2 >= 0
   node[i]                             = r;
   node[uint64_t(nnodes) + 2 * li]     = ba;  // body level continues the level-order numbering: nnodes = 2^nlevels - 1
   node[uint64_t(nnodes) + 2 * li + 1] = bb;
@@ -521,8 +522,9 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // which serves its four SIMDs in turn — so the step is written to be short in both:
 //   * the whole 64-byte record arrives with ONE s_load_dwordx16 whose address is base + a byte offset kept in an
 //     SGPR (off = 64 * level-order index: child = 2*off + 64, sibling = off + 64, parent + 1 = off / 2);
-//   * the sweep position is the packed key cur = covered << 5 | level plus shift = nlevels - level; both successors
-//     are one or two scalar operations away (descend: cur + 1; ascend: cur + (32 << shift) - right);
+//   * the sweep position is the packed key cur = covered << 5 | level plus span = 32 << (levels below the entry); both
+//     successors are one or two scalar operations away (descend: cur + 1; ascend: cur + span - right);
+//   * body records carry width^2 = -1, so "a body is always taken" falls out of the opening test itself (no level check);
 //   * the opening test's differences are reused by the accepted term, whose weight needs no reciprocal (tree_accumulate).
 // Measured and rejected earlier: fetching both possible successors speculatively (scalar loads return out of order,
 // so every step waits for the not-taken, often cold, one: 26 vs 14 ms); a wave-private LDS window over a
@@ -588,8 +590,13 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   uint32_t c_nodes[BPL] = {}, c_leaf[BPL] = {}, c_mono[BPL] = {}, c_body[BPL] = {};
 
   // wave-uniform position of the sweep, kept incrementally in SGPRs: packed key, levels below, byte offset of the record
-  uint32_t cur = 0, shift = nlevels, off = 0;
+  // packed key, 32 << (levels below the entry), byte offset of the record
+  uint32_t cur = 0, span = 32u << nlevels, off = 0;
   const uint32_t end_key = sz << 5;  // cur >= end_key: covered >= sz, every remaining key is >= cur: all lanes are finished
+#pragma unroll
+  for (int b = 0; b < BPL; ++b)
+#pragma unroll
+    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(xs[b][k]));  // the position loads complete here, not inside the loop
 
   while (cur < end_key) {
     auto raw = rec_sgprs<T>::load(node, off);  // wave-uniform address: one scalar load of the whole record
@@ -597,9 +604,9 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     // left child -> sibling (same level); right child -> parent + 1 (level - 1)   (src/bvh.h:272-281)
     // (an entry is a right child iff its level-order index is even; the root counts as one)
     const uint32_t right = ((off / RB) & 1u) ^ 1u;
-    const uint32_t ka    = cur + (32u << shift) - right;  // covered + 2^shift, level - right
-    const uint32_t kd    = cur + 1u;                      // descend: same covered, level + 1  (src/bvh.h:283-286)
-    const bool body      = shift == 0u;
+    const uint32_t ka    = cur + span - right;  // covered + 2^(levels below), level - right
+    const uint32_t kd    = cur + 1u;            // descend: same covered, level + 1  (src/bvh.h:283-286)
+    const bool body      = span == 32u;         // (counters only: body records pass the opening test by construction)
     rec_wait(raw);
     const tree_rec<T> rc = __builtin_bit_cast(tree_rec<T>, raw);
     uint64_t m_reject_any = 0ull, waiting = 0ull;
@@ -617,7 +624,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       }
       // the conditions as scalar masks from ballots of the two plain compares; lanes read them back for free
       const uint64_t m_active = __builtin_amdgcn_ballot_w64(key[b] == cur);
-      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(rc.v[D + 2] < scaled) | (body ? ~0ull : 0ull);
+      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(rc.v[D + 2] < scaled);
       const uint64_t m_accept = m_active & m_approx;
       const uint64_t m_reject = m_active & ~m_approx;
       const bool accept       = __builtin_amdgcn_inverse_ballot_w64(m_accept);
@@ -646,7 +653,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     // (parent + 1 = idx / 2 for an even idx; sibling = idx + 1) — unless some lane waits at a smaller key: it jumped there
     // from a deeper subtree, to an entry below the one just accepted by the others (rare; found and decoded below).
     const uint32_t off_down = 2u * off + RB, off_up = right ? (off >> 1) : off + RB;
-    const uint32_t sh_down = shift - 1u, sh_up = shift + right;
+    const uint32_t sh_down = span >> 1, sh_up = span << right;
     uint64_t behind;
     // four scalar selects on one condition; written out because hipcc turns the equivalent C++ into a diamond of branches
     asm volatile("s_cmp_lg_u64 %[mr], 0\n\t"
@@ -654,7 +661,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
                  "s_cselect_b32 %[off], %[od], %[ou]\n\t"
                  "s_cselect_b32 %[sh], %[sd], %[su]\n\t"
                  "s_cselect_b64 %[bh], 0, %[wt]"
-                 : [cur] "=&s"(cur), [off] "=&s"(off), [sh] "=&s"(shift), [bh] "=&s"(behind)
+                 : [cur] "=&s"(cur), [off] "=&s"(off), [sh] "=&s"(span), [bh] "=&s"(behind)
                  : [mr] "s"(m_reject_any), [kd] "s"(kd), [ka] "s"(ka), [od] "s"(off_down), [ou] "s"(off_up), [sd] "s"(sh_down),
                    [su] "s"(sh_up), [wt] "s"(waiting)
                  : "scc");
@@ -674,7 +681,8 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       }
       cur                  = cand;
       const uint32_t level = cand & 31u;
-      shift                = nlevels - level;
+      const uint32_t shift = nlevels - level;
+      span                 = 32u << shift;
       off                  = (((1u << level) - 1u) + ((cand >> 5) >> shift)) * RB;
     }
     cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR

@@ -462,7 +462,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     bool take;
     {
 #pragma clang fp contract(off)
-      take = body || rec.v[D + 2] < theta2 * d2;
+      take = rec.v[D + 2] < theta2 * d2;  // body records carry width^2 = -1: always taken
     }
     uint32_t n_index, n_level = level, n_cov = covered;
     if (take) {

@@ -115,6 +115,15 @@ class ShardedAllPairs:
             return
         end = self.first + self.count
         self.send[:self.count].copy_(self.x[self.first:end])
+        if self.x.is_cuda and self.dist.get_backend() == "gloo":
+            # device tensors under a CPU process group (the two-ranks-on-one-GPU test): stage the shards through the host
+            send = self.send.cpu()
+            recv = [self.torch.empty_like(send) for _ in range(self.world)]
+            self.dist.all_gather(recv, send)
+            for r, (f, e) in enumerate(self.shards):
+                if r != self.rank:
+                    self.x[f:e].copy_(recv[r][:e - f].to(self.device))
+            return
         self.dist.all_gather_into_tensor(self.recv, self.send)
         for r, (f, e) in enumerate(self.shards):
             if r != self.rank:

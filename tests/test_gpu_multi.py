@@ -108,3 +108,54 @@ def test_sharded_context_download_places_rows(nb):
     for d, f, e in parts:
         nb._check(nb.lib().nbody_download(d.h, nb._p(out.m), nb._p(out.x), nb._p(out.v), nb._p(out.a), nb._p(out.ao)))
     assert np.array_equal(out.x, ref.x) and np.array_equal(out.v, ref.v) and np.array_equal(out.a, ref.a)
+
+
+def _two_rank_worker(rank, world, port, n, steps, q):
+    """One of two real rank processes sharing the box's one GPU: HIP kernels on its shard window, K3, exchange."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import load_package
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one device: CPU group, staged exchange
+    nb = load_package()
+    torch.cuda.set_device(0)
+    hs = nb.build_model(nb.F64, 3, "galaxy", n)
+    sim = nb.parallel.ShardedAllPairs(hs, rank, world, torch_device=torch.device("cuda", 0))
+    for _ in range(steps):
+        sim.step()
+    torch.cuda.synchronize()
+    x, v, a = sim.gather_state()
+    if rank == 0:
+        q.put((x, v, a))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n,world", [(70001, 2), (8192, 3)])
+def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world):
+    """ranks as real processes, each launching the HIP kernels on its own shard window and exchanging positions
+    every step, against the single-GPU trajectory — bitwise in x, v, a.  Both ranks use the box's one MI355X, so the
+    process group is gloo and the shards are staged through the host (the RCCL exchange itself needs one GPU per rank);
+    70001 bodies: uneven shards, the 8-slice scalar-stream K1 with source chunks."""
+    import socket
+    import torch.multiprocessing as mp
+    steps = 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    x, v, a = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "galaxy", n))
+    nb.run(dev, "all-pairs", steps)
+    ref = dev.download()
+    assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)

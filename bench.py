@@ -187,7 +187,8 @@ def launch_ranks(args):
     everything else to stderr, and exits with the launcher's status."""
     import socket
     have = visible_gpus()
-    if have < args.gpus:
+    share = os.environ.get("NBODY_BENCH_SHARE_GPU") == "1"  # rehearsal: all ranks on device 0 (see main)
+    if have < (1 if share else args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible to this process")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -251,17 +252,27 @@ def main():
                          f"or with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    # NBODY_BENCH_SHARE_GPU=1: a REHEARSAL of the multi-rank code path on a box with one GPU — every rank uses device 0,
+    # the process group is gloo and the position shards are staged through the host (RCCL refuses two ranks on one device).
+    # The line it prints is marked as such and is not a measurement.
+    share_gpu = os.environ.get("NBODY_BENCH_SHARE_GPU") == "1" and world > 1
+    if share_gpu:
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU ({torch.cuda.device_count()} visible)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if share_gpu else dev  # where the small control reductions live
     # NBODY_BENCH_FORCE_DIST=1 exercises the whole multi-rank path (launcher, process group, communicator, barrier,
     # all-gather, max-reduce) even with one rank
     use_dist = world > 1 or force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nb = load_package()
     par = nb.parallel
@@ -269,7 +280,9 @@ def main():
     # the data-path collective is the library's own (nbody_allgather_positions, RCCL behind the C ABI); torch.distributed
     # is the launcher's side: it carries the RCCL unique id to the ranks, the barriers and the max-over-ranks of the time
     comm, comm_note = None, None
-    if use_dist:
+    if share_gpu:
+        comm_note = "REHEARSAL: %d ranks share one GPU, gloo group, shards staged through the host" % world
+    elif use_dist:
         # Every rank must end up on the same exchange: if the communicator cannot be created on ANY rank (RCCL not loadable
         # through dlopen, a version clash with the copy PyTorch mapped), all ranks use the torch.distributed form of the
         # same all-gather (still RCCL) and the line says so.
@@ -286,7 +299,7 @@ def main():
                 comm = nb.Comm(world, rank, box[0], local_rank)
             except Exception as ex:
                 ok, err = 0, str(ex)
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if comm is not None:
@@ -307,7 +320,7 @@ def main():
         # after a step every rank must hold the same positions: two checksums of the full x, compared across the ranks
         # (a rank whose exchange did not deliver would keep stale rows, and the number below would mean nothing)
         wts = torch.arange(1, sim.x.numel() + 1, dtype=torch.float64, device=dev).reshape(sim.x.shape)
-        sums = torch.stack([sim.x.sum(), (sim.x * wts).sum()])
+        sums = torch.stack([sim.x.sum(), (sim.x * wts).sum()]).to(red_dev)
         lo, hi = sums.clone(), sums.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
@@ -334,7 +347,7 @@ def main():
     if telemetry:
         telemetry.__exit__()
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -353,6 +366,7 @@ def main():
         row = 3 * 8  # bytes of one position record (3D double)
         out = {
             "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
+            **({"rehearsal": comm_note} if share_gpu else {}),
             "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

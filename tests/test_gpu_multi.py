@@ -159,3 +159,14 @@ def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world):
     nb.run(dev, "all-pairs", steps)
     ref = dev.download()
     assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
+
+
+def test_bench_multi_rank_rehearsal_on_one_gpu():
+    """`python bench.py --gpus 2` as typed, rehearsed on the one-GPU box (NBODY_BENCH_SHARE_GPU=1: both ranks on device 0,
+    gloo group, staged exchange): the launcher starts two ranks, every rank-dependent branch of bench.py runs (shards, the
+    cross-rank position check, max-over-ranks of the time), rank 0's single line is relayed and marked as a rehearsal."""
+    out = _bench({"NBODY_BENCH_SHARE_GPU": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--bodies", str(1 << 16), "--no-cpu-baseline")
+    assert out["n_gpus"] == 2 and out["shards"] == [1 << 15, 1 << 15] and "REHEARSAL" in out["rehearsal"]
+    assert out["rccl_world"]["world"] == 2 and out["rccl_world"]["backend"] == "gloo"
+    assert "identical on all 2 rank(s)" in out["rccl_world"]["exchange_check"]
+    assert out["allgather"]["sent_bytes_per_rank_per_step"] == (1 << 15) * 24 and out["value"] > 0

@@ -240,3 +240,16 @@ def test_gpus_flag_multi_device_path_on_one_gpu():
     assert r.returncode != 0 and "all-pairs only" in r.stderr
     r = cli_env(3, ["-n", 1000, "-s", 2, "--algorithm", "all-pairs", "--gpus", 1, "--save", "energy", "--csv-detailed"], {"NBODY_CLI_FORCE_COMM": "1"})
     assert r.returncode != 0 and "one GPU only" in r.stderr
+
+
+def test_multi_gpu_abi_from_plain_c(tmp_path):
+    """examples/abi_multi_gpu.c: contexts with shard windows, nbody_comm_create_all and nbody_allgather_positions from C99,
+    compared bitwise with a single whole-system context (run with the one device this box has)."""
+    libdir = os.path.join(ROOT, "stdpar-nbody_amd")
+    exe = str(tmp_path / "abi_multi_gpu")
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "examples", "abi_multi_gpu.c"), "-L" + libdir, "-lnbody_hip", "-Wl,-rpath," + libdir,
+                        "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "bitwise equal" in r.stdout, r.stdout + r.stderr

@@ -85,9 +85,16 @@ class ShardedAllPairs:
         self.comm = comm                             # nbody_comm (C ABI): the exchange of the GPU path
         self.shards = [shard_range(hs.n, r, world) for r in range(world)]
         self.maxc = max(e - f for f, e in self.shards)
-        if self.exchange and comm is None:           # torch.distributed form: one all_gather over padded shards
-            self.send = torch.zeros((self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
-            self.recv = torch.empty((world * self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
+        if self.exchange and comm is None:
+            self.use_torch_exchange()
+
+    def use_torch_exchange(self):
+        """Switch to the torch.distributed form of the exchange: one all_gather over padded shards (also the fallback
+        bench.py takes when the library's communicator cannot be created or fails its cross-rank check)."""
+        torch = self.torch
+        self.comm = None
+        self.send = torch.zeros((self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
+        self.recv = torch.empty((self.world * self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
 
     def state(self, whole=False):
         """The shard's view; whole=True: the window covers every body (phases that read only m and x)."""

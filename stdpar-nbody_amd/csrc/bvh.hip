@@ -55,6 +55,7 @@ struct nbody_bvh {
   void* node      = nullptr;
   void* box       = nullptr;
   uint32_t* counters = nullptr;
+  uint32_t* order = nullptr;  // K9 sweep: groups of each XCD's range, the few that straddle a jump of the key order first
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
@@ -557,6 +558,89 @@ __device__ __forceinline__ void rec_wait(V& v) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
 }
 
+// Launch order of the sweep.  A wave's sweep is 2.9k-14.2k steps long (config 4: mean 7.4k, p90 9.0k); the longest belong to
+// the ~1-2 % of groups whose 64 consecutive bodies straddle a jump of the reference's key order (bounding-box diagonals of
+// 20-70 length units against a median of 5), a SIMD slot runs only about two waves per launch, and blocks start in index
+// order — a long sweep that starts late is the tail of the kernel.  The jump shows in the keys themselves: the highest bit
+// in which a group's first and last key differ.  Inside each XCD's contiguous range of groups (xcd_contiguous_block's
+// ranges: the L2 neighbourhood of everything else is kept) the few groups with the highest such bit start first, the
+// rest keep their index order.  Nothing but the start order changes; results cannot depend on it.
+constexpr uint32_t kOrderMax = 8192;  // groups per XCD range one block orders (N <= 4.2M bodies); more: index order
+__device__ __forceinline__ void xcd_range(uint32_t xcd, uint32_t nblocks, uint32_t* start, uint32_t* len) {
+  const uint32_t q = nblocks / 8u, r = nblocks % 8u;
+  *start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  *len   = q + (xcd < r ? 1u : 0u);
+}
+
+__global__ __launch_bounds__(1024) void bvh_order_kernel(const uint64_t* __restrict__ sorted_keys, uint32_t first, uint32_t count,
+                                                          uint32_t* __restrict__ order, uint32_t nblocks, uint32_t divisor) {
+  __shared__ uint8_t lvl[kOrderMax];
+  __shared__ uint32_t hist[65], tsum[1024], outl[1024];
+  __shared__ uint32_t thr, nout;
+  uint32_t start, len;
+  xcd_range(blockIdx.x, nblocks, &start, &len);
+  const uint32_t t = threadIdx.x;
+  if (len > kOrderMax || len == 0) {
+    for (uint32_t i = t; i < len; i += blockDim.x) order[start + i] = start + i;
+    return;
+  }
+  if (t < 65) hist[t] = 0;
+  if (t == 0) nout = 0;
+  __syncthreads();
+  for (uint32_t i = t; i < len; i += blockDim.x) {
+    const uint32_t b0 = (start + i) * 64u, b1 = min(b0 + 63u, count - 1u);
+    const uint64_t d  = sorted_keys[first + b0] ^ sorted_keys[first + b1];
+    const uint32_t l  = d ? 64u - uint32_t(__builtin_clzll(d)) : 0u;
+    lvl[i]            = uint8_t(l);
+    atomicAdd(&hist[l], 1u);
+  }
+  __syncthreads();
+  if (t == 0) {  // the smallest level such that at most len / divisor (and at most 1024) of the groups lie at or above it
+    const uint32_t budget = min(1024u, len / divisor);
+    uint32_t acc = 0, l = 64;
+    while (l > 0 && acc + hist[l] <= budget) acc += hist[l--];
+    thr = l + 1;
+  }
+  __syncthreads();
+  const uint32_t th = thr;
+  // stable partition: outliers (collected, then ranked by level) first, everything else behind them in index order
+  const uint32_t per = (len + blockDim.x - 1) / blockDim.x, lo = min(len, t * per), hi = min(len, lo + per);
+  uint32_t mine = 0;
+  for (uint32_t i = lo; i < hi; ++i) mine += lvl[i] >= th;
+  tsum[t] = mine;
+  __syncthreads();
+  if (t == 0) {
+    uint32_t run = 0;
+    for (uint32_t k = 0; k < blockDim.x; ++k) {
+      const uint32_t v = tsum[k];
+      tsum[k]          = run;
+      run += v;
+    }
+    nout = run;
+  }
+  __syncthreads();
+  uint32_t before = tsum[t];
+  const uint32_t total_out = nout;
+  for (uint32_t i = lo; i < hi; ++i) {
+    if (lvl[i] >= th) outl[before++] = i;
+    else order[start + total_out + (i - before)] = start + i;
+  }
+  __syncthreads();
+  for (uint32_t k = t; k < total_out; k += blockDim.x) {
+    const uint32_t i = outl[k];
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < total_out; ++j) rank += lvl[outl[j]] > lvl[i] || (lvl[outl[j]] == lvl[i] && j < k);
+    order[start + rank] = start + i;
+  }
+}
+
+// group of this block: the XCD it runs on (block index mod 8) owns one contiguous range of groups
+__device__ __forceinline__ uint32_t ordered_group(const uint32_t* __restrict__ order, uint32_t b, uint32_t nblocks) {
+  uint32_t start, len;
+  xcd_range(b % 8u, nblocks, &start, &len);
+  return order[start + b / 8u];
+}
+
 // BPL bodies per lane: the wave sweeps the union of 64 * BPL consecutive (Hilbert-adjacent) bodies' walks.  The union
 // grows slowly with the group (about 7.4k entries for 64 bodies, 8k for 128 at config 4) while the scalar half of a step —
 // load, successors, position update: as many issue slots as the vector half — is paid once per step, and the BPL
@@ -565,10 +649,11 @@ template <typename T, int D, int BPL, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
-                                                            uint32_t* __restrict__ counters) {
+                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ order) {
   constexpr uint32_t DONE = 0xffffffffu;
   constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
-  const uint32_t base = xcd_contiguous_block(blockIdx.x, gridDim.x) * (64u * BPL) + threadIdx.x;
+  const uint32_t group = order ? ordered_group(order, blockIdx.x, gridDim.x) : xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const uint32_t base  = group * (64u * BPL) + threadIdx.x;
   const pair_consts<T> pc;
   T xs[BPL][D], acc[BPL][D];
   uint32_t key[BPL], bi[BPL];
@@ -800,12 +885,24 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 #define NB_ARGS                                                                                                   \
   dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, \
    s->count, th2, t->nlevels, t->counters
+  const uint32_t* order = nullptr;
+  const char* oe        = getenv("NBODY_K9_ORDER");  // experiments: 0 = plain index order
+  if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && !(oe && oe[0] == '0')) {
+    // groups that straddle a jump of the key order start first (bvh_order_kernel); the sorted keys are in keys[1]
+    // measured in the CLI's step loop (ms per whole bvh step, index order / this order): N = 10^6 8.05 / 7.4, 5*10^5 5.3 / 4.6;
+    // flat for any share of early starters between 1.5 % and 50 % of the groups
+    uint32_t divisor = 16;
+    if (oe && atoi(oe) > 1) divisor = uint32_t(atoi(oe));
+    hipLaunchKernelGGL(bvh_order_kernel, dim3(8), dim3(1024), 0, st, t->keys[1], s->first, s->count, t->order, blocks, divisor);
+    NB_HIP(hipGetLastError());
+    order = t->order;
+  }
   if (wave && bpl == 2) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS, order);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS, order);
   } else if (wave) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS, order);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS, order);
   } else {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
     else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
@@ -867,6 +964,7 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
+  NB_ALLOC(t->order, sizeof(uint32_t) * ((size_t(n) + 63) / 64));
 #undef NB_ALLOC
   *out = t;
   return NBODY_OK;
@@ -886,6 +984,7 @@ extern "C" void nbody_bvh_destroy(nbody_bvh* t) {
   (void)hipFree(t->node);
   (void)hipFree(t->box);
   (void)hipFree(t->counters);
+  (void)hipFree(t->order);
   delete t;
 }
 

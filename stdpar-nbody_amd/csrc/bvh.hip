@@ -55,7 +55,8 @@ struct nbody_bvh {
   void* node      = nullptr;
   void* box       = nullptr;
   uint32_t* counters = nullptr;
-  uint32_t* order = nullptr;  // K9 sweep: groups of each XCD's range, the few that straddle a jump of the key order first
+  uint32_t* order   = nullptr;  // K9 sweep: 8 lists of work items (one per XCD), see bvh_items_kernel
+  uint32_t* order_n = nullptr;  // items per list
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
@@ -558,52 +559,67 @@ __device__ __forceinline__ void rec_wait(V& v) {
   asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
 }
 
-// Launch order of the sweep.  A wave's sweep is 2.9k-14.2k steps long (config 4: mean 7.4k, p90 9.0k); the longest belong to
+// Work items of the sweep.  A wave's sweep is 2.9k-14.2k steps long (config 4: mean 7.4k, p90 9.0k); the longest belong to
 // the ~1-2 % of groups whose 64 consecutive bodies straddle a jump of the reference's key order (bounding-box diagonals of
-// 20-70 length units against a median of 5), a SIMD slot runs only about two waves per launch, and blocks start in index
-// order — a long sweep that starts late is the tail of the kernel.  The jump shows in the keys themselves: the highest bit
-// in which a group's first and last key differ.  Inside each XCD's contiguous range of groups (xcd_contiguous_block's
-// ranges: the L2 neighbourhood of everything else is kept) the few groups with the highest such bit start first, the
-// rest keep their index order.  Nothing but the start order changes; results cannot depend on it.
-constexpr uint32_t kOrderMax = 8192;  // groups per XCD range one block orders (N <= 4.2M bodies); more: index order
-__device__ __forceinline__ void xcd_range(uint32_t xcd, uint32_t nblocks, uint32_t* start, uint32_t* len) {
+// 20-70 length units against a median of 5): their unions are 2-3.5x a body's walk.  A SIMD slot runs only about two waves
+// per launch and blocks start in index order, so a long sweep that starts late is the tail of the kernel, and the longest
+// one is its critical path (14k steps at ~1300 cycles each is the whole 8 ms).  The jump shows in the sorted keys: the
+// highest bit in which two keys differ.  Per XCD range of groups (xcd_contiguous_block's ranges, so the L2 neighbourhood of
+// everything else is kept) bvh_items_kernel
+//   * takes the len / 16 groups whose first and last key differ in the highest bit,
+//   * cuts each of them at its largest internal jump into two work items (lanes [0, cut) and [cut, 64) of the same group:
+//     two compact half-groups sweep two short unions side by side instead of one long one), and
+//   * lists those items first, highest jump first; every other group follows as one item in index order.
+// item = group | first lane << 20 | last lane << 26.  Nothing but grouping and start order changes: a body's result depends
+// on the tree and that body alone.
+constexpr uint32_t kOrderMax = 8192;  // groups per XCD range one block handles (N <= 4.2M bodies); more: plain index order
+constexpr uint32_t kSplitMax = 512;   // groups per XCD range that may be cut
+__host__ __device__ __forceinline__ void xcd_range(uint32_t xcd, uint32_t nblocks, uint32_t* start, uint32_t* len) {
   const uint32_t q = nblocks / 8u, r = nblocks % 8u;
   *start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
   *len   = q + (xcd < r ? 1u : 0u);
 }
+__host__ __device__ __forceinline__ uint32_t split_budget(uint32_t len) {
+  const uint32_t b = len / 16u;
+  return len > kOrderMax ? 0u : (b < kSplitMax ? b : kSplitMax);
+}
+__device__ __forceinline__ uint32_t pack_item(uint32_t group, uint32_t lo, uint32_t hi) { return group | (lo << 20) | (hi << 26); }
 
-__global__ __launch_bounds__(1024) void bvh_order_kernel(const uint64_t* __restrict__ sorted_keys, uint32_t first, uint32_t count,
-                                                          uint32_t* __restrict__ order, uint32_t nblocks, uint32_t divisor) {
+// items of XCD x live at items[x * stride ...], nitems[x] of them; stride = longest range + its budget
+__global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restrict__ sorted_keys, uint32_t first, uint32_t count,
+                                                          uint32_t* __restrict__ items, uint32_t* __restrict__ nitems,
+                                                          uint32_t nblocks, uint32_t stride) {
   __shared__ uint8_t lvl[kOrderMax];
-  __shared__ uint32_t hist[65], tsum[1024], outl[1024];
+  __shared__ uint32_t hist[65], tsum[1024], outl[kSplitMax];
   __shared__ uint32_t thr, nout;
   uint32_t start, len;
   xcd_range(blockIdx.x, nblocks, &start, &len);
+  uint32_t* out    = items + blockIdx.x * stride;
   const uint32_t t = threadIdx.x;
   if (len > kOrderMax || len == 0) {
-    for (uint32_t i = t; i < len; i += blockDim.x) order[start + i] = start + i;
+    for (uint32_t i = t; i < len; i += blockDim.x) out[i] = pack_item(start + i, 0, 63);
+    if (t == 0) nitems[blockIdx.x] = len;
     return;
   }
   if (t < 65) hist[t] = 0;
-  if (t == 0) nout = 0;
   __syncthreads();
+  auto jump = [](uint64_t a, uint64_t b) { return a == b ? 0u : 64u - uint32_t(__builtin_clzll(a ^ b)); };
   for (uint32_t i = t; i < len; i += blockDim.x) {
     const uint32_t b0 = (start + i) * 64u, b1 = min(b0 + 63u, count - 1u);
-    const uint64_t d  = sorted_keys[first + b0] ^ sorted_keys[first + b1];
-    const uint32_t l  = d ? 64u - uint32_t(__builtin_clzll(d)) : 0u;
+    const uint32_t l  = jump(sorted_keys[first + b0], sorted_keys[first + b1]);
     lvl[i]            = uint8_t(l);
     atomicAdd(&hist[l], 1u);
   }
   __syncthreads();
-  if (t == 0) {  // the smallest level such that at most len / divisor (and at most 1024) of the groups lie at or above it
-    const uint32_t budget = min(1024u, len / divisor);
+  if (t == 0) {  // the smallest level such that at most split_budget(len) groups lie at or above it
+    const uint32_t budget = split_budget(len);
     uint32_t acc = 0, l = 64;
     while (l > 0 && acc + hist[l] <= budget) acc += hist[l--];
     thr = l + 1;
   }
   __syncthreads();
   const uint32_t th = thr;
-  // stable partition: outliers (collected, then ranked by level) first, everything else behind them in index order
+  // stable partition: the groups to cut are collected, everything else goes behind their 2 * nout items in index order
   const uint32_t per = (len + blockDim.x - 1) / blockDim.x, lo = min(len, t * per), hi = min(len, lo + per);
   uint32_t mine = 0;
   for (uint32_t i = lo; i < hi; ++i) mine += lvl[i] >= th;
@@ -616,29 +632,38 @@ __global__ __launch_bounds__(1024) void bvh_order_kernel(const uint64_t* __restr
       tsum[k]          = run;
       run += v;
     }
-    nout = run;
+    nout                = run;
+    nitems[blockIdx.x]  = len + run;
   }
   __syncthreads();
-  uint32_t before = tsum[t];
+  uint32_t before          = tsum[t];
   const uint32_t total_out = nout;
   for (uint32_t i = lo; i < hi; ++i) {
     if (lvl[i] >= th) outl[before++] = i;
-    else order[start + total_out + (i - before)] = start + i;
+    else out[2 * total_out + (i - before)] = pack_item(start + i, 0, 63);
   }
   __syncthreads();
   for (uint32_t k = t; k < total_out; k += blockDim.x) {
     const uint32_t i = outl[k];
     uint32_t rank = 0;
     for (uint32_t j = 0; j < total_out; ++j) rank += lvl[outl[j]] > lvl[i] || (lvl[outl[j]] == lvl[i] && j < k);
-    order[start + rank] = start + i;
+    // the cut: behind the largest jump between consecutive keys of the group (first one wins)
+    const uint32_t b0 = (start + i) * 64u, nb = min(64u, count - b0);
+    uint32_t cut = nb / 2u, best = 0;
+    uint64_t prev = sorted_keys[first + b0];
+    for (uint32_t j = 1; j < nb; ++j) {
+      const uint64_t cur = sorted_keys[first + b0 + j];
+      const uint32_t l   = jump(prev, cur);
+      if (l > best) {
+        best = l;
+        cut  = j;
+      }
+      prev = cur;
+    }
+    if (cut == 0 || cut >= nb) cut = nb > 1 ? nb / 2u : 1u;
+    out[2 * rank]     = pack_item(start + i, 0, cut - 1u);
+    out[2 * rank + 1] = nb > cut ? pack_item(start + i, cut, 63) : pack_item(start + i, 63, 0);  // empty range: no lane
   }
-}
-
-// group of this block: the XCD it runs on (block index mod 8) owns one contiguous range of groups
-__device__ __forceinline__ uint32_t ordered_group(const uint32_t* __restrict__ order, uint32_t b, uint32_t nblocks) {
-  uint32_t start, len;
-  xcd_range(b % 8u, nblocks, &start, &len);
-  return order[start + b / 8u];
 }
 
 // BPL bodies per lane: the wave sweeps the union of 64 * BPL consecutive (Hilbert-adjacent) bodies' walks.  The union
@@ -649,11 +674,21 @@ template <typename T, int D, int BPL, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
-                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ order) {
+                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
+                                                            const uint32_t* __restrict__ nitems, uint32_t stride) {
   constexpr uint32_t DONE = 0xffffffffu;
   constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
-  const uint32_t group = order ? ordered_group(order, blockIdx.x, gridDim.x) : xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const uint32_t base  = group * (64u * BPL) + threadIdx.x;
+  // work item of this block: with an item list, the XCD it runs on (block index mod 8) owns one list (bvh_items_kernel)
+  uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
+  if (items) {
+    const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+    if (slot >= nitems[xcd]) return;
+    const uint32_t it = items[xcd * stride + slot];
+    group   = it & 0xfffffu;
+    lane_lo = (it >> 20) & 63u;
+    lane_hi = it >> 26;
+  }
+  const uint32_t base = group * (64u * BPL) + threadIdx.x;
   const pair_consts<T> pc;
   T xs[BPL][D], acc[BPL][D];
   uint32_t key[BPL], bi[BPL];
@@ -663,7 +698,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
 #pragma unroll
   for (int b = 0; b < BPL; ++b) {
     const uint32_t local = base + 64u * b;
-    valid[b]             = local < count;
+    valid[b]             = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
     bi[b]                = first + (valid[b] ? local : 0u);
     key[b]               = valid[b] ? 0u : DONE;  // root: covered 0, level 0
 #pragma unroll
@@ -885,29 +920,38 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 #define NB_ARGS                                                                                                   \
   dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, \
    s->count, th2, t->nlevels, t->counters
-  const uint32_t* order = nullptr;
-  const char* oe        = getenv("NBODY_K9_ORDER");  // experiments: 0 = plain index order
+  const uint32_t *items = nullptr, *nitems = nullptr;
+  uint32_t stride = 0, wave_blocks = blocks;
+  const char* oe = getenv("NBODY_K9_ORDER");  // experiments: 0 = one block per group in index order
   if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && !(oe && oe[0] == '0')) {
-    // groups that straddle a jump of the key order start first (bvh_order_kernel); the sorted keys are in keys[1]
-    // measured in the CLI's step loop (ms per whole bvh step, index order / this order): N = 10^6 8.05 / 7.4, 5*10^5 5.3 / 4.6;
-    // flat for any share of early starters between 1.5 % and 50 % of the groups
-    uint32_t divisor = 16;
-    if (oe && atoi(oe) > 1) divisor = uint32_t(atoi(oe));
-    hipLaunchKernelGGL(bvh_order_kernel, dim3(8), dim3(1024), 0, st, t->keys[1], s->first, s->count, t->order, blocks, divisor);
+    // Work items (bvh_items_kernel): groups that straddle a jump of the key order are cut in two and start first.  Measured
+    // in the CLI's step loop (ms per whole bvh step; index order / start order only / start order + cut): N = 10^6 8.05 / 7.4 /
+    // 7.4, 5*10^5 5.3 / 4.6 / 4.3.  The sorted keys are in keys[1] (8 radix passes end in the buffer they started from).
+    uint32_t s0, l0;
+    xcd_range(0, blocks, &s0, &l0);  // XCD 0 has the longest range
+    stride      = l0 + split_budget(l0);
+    wave_blocks = 8u * stride;       // blocks are dealt round-robin over the XCDs: 8 lists of up to `stride` items
+    hipLaunchKernelGGL(bvh_items_kernel, dim3(8), dim3(1024), 0, st, t->keys[1], s->first, s->count, t->order, t->order_n, blocks,
+                       stride);
     NB_HIP(hipGetLastError());
-    order = t->order;
+    items  = t->order;
+    nitems = t->order_n;
   }
+#define NB_WARGS                                                                                                             \
+  dim3(wave_blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
+   s->first, s->count, th2, t->nlevels, t->counters, items, nitems, stride
   if (wave && bpl == 2) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_ARGS, order);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_ARGS, order);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
   } else if (wave) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_ARGS, order);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_ARGS, order);
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
   } else {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
     else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
   }
 #undef NB_ARGS
+#undef NB_WARGS
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -964,7 +1008,8 @@ extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n)
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
-  NB_ALLOC(t->order, sizeof(uint32_t) * ((size_t(n) + 63) / 64));
+  NB_ALLOC(t->order, sizeof(uint32_t) * (((size_t(n) + 63) / 64 / 8 + 1) * 17 / 16 + 8) * 8);  // 8 x (longest range + budget)
+  NB_ALLOC(t->order_n, sizeof(uint32_t) * 8);
 #undef NB_ALLOC
   *out = t;
   return NBODY_OK;
@@ -985,6 +1030,7 @@ extern "C" void nbody_bvh_destroy(nbody_bvh* t) {
   (void)hipFree(t->box);
   (void)hipFree(t->counters);
   (void)hipFree(t->order);
+  (void)hipFree(t->order_n);
   delete t;
 }
 

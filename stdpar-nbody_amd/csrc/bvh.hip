@@ -902,11 +902,13 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th  = static_cast<T>(theta);
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
-  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured on 256 CUs (f64,
-  // sweep / per-lane): 9.55 / 20.2 ms at 10^6, 5.93 / 8.40 at 5*10^5, 4.13 / 4.58 at 3*10^5, 4.26 / 2.63 at 2*10^5, 2.84 / 1.17 at 10^5;
-  // f32 7.79 / 12.6 ms at 10^6, 4.02 / 3.94 at 4*10^5.
-  const uint32_t crossover = sizeof(T) == 8 ? 280000u : 400000u;
-  const bool wave = t->traversal >= 2 || (t->traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
+  // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
+  // 256 CUs (ms per whole bvh step over 200 steps, sweep / per-lane): f64 1.55 / 1.25 at 10^5, 1.85 / 1.80 at 1.5*10^5, 2.25 / 2.55
+  // at 2*10^5, 2.65 / 3.9 at 3*10^5; f32 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.
+  const uint32_t crossover = sizeof(T) == 8 ? 160000u : 250000u;
+  int traversal = t->traversal;
+  if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
+  const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;
@@ -914,7 +916,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // Bodies per lane of the sweep: 1.  With 2 (128 bodies per wave: half the waves, the scalar half of every step shared)
   // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
   // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
-  const int bpl            = t->traversal == 4 ? 2 : 1;
+  const int bpl            = traversal == 4 ? 2 : 1;
   const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
   const uint32_t blocks    = (s->count + per_block - 1) / per_block;
 #define NB_ARGS                                                                                                   \

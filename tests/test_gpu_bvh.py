@@ -215,3 +215,35 @@ def test_traversal_shard_windows_bitwise(nb):
             t.compute_force(dev.state(f, c), 0.5, dev.stream)
         assert np.array_equal(dev.download().a, full), mode
         dev.close()
+
+
+def test_sweep_work_items_and_shard_windows(nb):
+    """The sweep's work items (key-jump groups cut in two and started first, tests 1/16 of the groups) change grouping and
+    start order only: windows of the bodies, every scheduling form and the plain index order (NBODY_K9_ORDER=0) give bitwise
+    the same accelerations and counters — also where the window does not start at a group boundary."""
+    import os
+    n = 200003
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    st, t = dev.state(), dev.bvh
+    t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
+    t.enable_counters(True)
+    res = {}
+    for mode, env in ((1, None), (3, None), (3, "0"), (4, None)):
+        if env is not None:
+            os.environ["NBODY_K9_ORDER"] = env
+        try:
+            t.set_traversal(mode)
+            t.compute_force(st, 0.5, dev.stream)
+            dev.sync()
+            res[(mode, env)] = (dev.download().a.copy(), t.read(5, dev.stream).copy())
+        finally:
+            os.environ.pop("NBODY_K9_ORDER", None)
+    base = res[(1, None)]
+    for k, r in res.items():
+        assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), k
+    t.set_traversal(3)
+    for first, count in ((0, 70000), (70000, 65539), (135539, n - 135539)):
+        w = dev.state(first, count)
+        t.compute_force(w, 0.5, dev.stream)
+    dev.sync()
+    assert np.array_equal(dev.download().a, base[0])

@@ -307,6 +307,12 @@ def test_config5_rank_windows_at_2pow20(nb, oracle):
     ref = oracle.State(1, 3, n)
     ref.m[:], ref.x[:], ref.c = hs.m, hs.x, hs.c
     rng = np.random.default_rng(5)
+    for world, k in ((2, 1), (4, 2)):   # the windows of a 2- and a 4-GPU run: bitwise the single-GPU rows as well
+        f, e = nb.shard_range(n, k, world)
+        d2 = nb.DeviceSystem.from_host(hs)
+        d2.all_pairs_force(f, e - f)
+        assert np.array_equal(d2.download().a[f:e], full[f:e]), (world, k)
+        d2.close()
     for k in (0, 3, 7):
         assert nb.shard_range(n, k, 8) == (k * w, (k + 1) * w)
         d2 = nb.DeviceSystem.from_host(hs)

@@ -464,7 +464,9 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     bool take;
     {
 #pragma clang fp contract(off)
-      take = rec.v[D + 2] < theta2 * d2;  // body records carry width^2 = -1: always taken
+      // the reference's  bw*bw < theta^2*d2  for numbers; a NaN distance accepts, so that no walk can descend below the
+      // body level (records carry width^2 = -1: always taken) whatever the state holds
+      take = !(rec.v[D + 2] >= theta2 * d2);
     }
     uint32_t n_index, n_level = level, n_cov = covered;
     if (take) {
@@ -712,7 +714,10 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   // wave-uniform position of the sweep, kept incrementally in SGPRs: packed key, levels below, byte offset of the record
   // packed key, 32 << (levels below the entry), byte offset of the record
   uint32_t cur = 0, span = 32u << nlevels, off = 0;
-  const uint32_t end_key = sz << 5;  // cur >= end_key: covered >= sz, every remaining key is >= cur: all lanes are finished
+  // cur >= (sz << 5): covered >= sz, every remaining key is >= cur: all lanes are finished.  One less, because an accepted
+  // ROOT (theta > 0.58) is left by the ascend rule with covered + 2^nlevels and level - 1 = 31 after the borrow, which is
+  // (sz << 5) - 1 when sz is a power of two; no live key has level 31.
+  const uint32_t end_key = (sz << 5) - 1u;
 #pragma unroll
   for (int b = 0; b < BPL; ++b)
 #pragma unroll
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
       }
       // the conditions as scalar masks from ballots of the two plain compares; lanes read them back for free
       const uint64_t m_active = __builtin_amdgcn_ballot_w64(key[b] == cur);
-      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(rc.v[D + 2] < scaled);
+      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(!(rc.v[D + 2] >= scaled));  // `<` for numbers; NaN accepts
       const uint64_t m_accept = m_active & m_approx;
       const uint64_t m_reject = m_active & ~m_approx;
       const bool accept       = __builtin_amdgcn_inverse_ballot_w64(m_accept);
@@ -819,6 +824,236 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
         counters[uint64_t(bi[b]) * 4 + 2] = c_mono[b];
         counters[uint64_t(bi[b]) * 4 + 3] = c_body[b];
       }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9, the sweep's step program written out as ISA (f64).
+//
+// The sweep above is bound by the number of instructions a step issues (vector and scalar halves barely overlap: a wave's
+// step is one dependent chain).  hipcc's schedule of the C++ step is 61 instructions; this is the same step — same tests,
+// same arithmetic in the same order, bitwise the same results and counters — written for the machine:
+//   * execution masks instead of selects: v_cmpx puts the lanes standing on the current entry in EXEC, the difference /
+//     distance / opening-test arithmetic runs for them alone, a second v_cmpx narrows EXEC to the lanes that accept, and the
+//     accepted term plus `key = skip key` run under it; the lanes that open the entry get `key + 1` under
+//     EXEC = match & ~accept.  No v_cndmask, no mask round trips, and the s_andn2 that builds the last mask is also the
+//     test for "somebody descends" (its SCC);
+//   * the position is (cur, off, span - 1): the skip key is ONE s_addc_u32 (cur + (span - 1) + "is a left child", the latter
+//     read by s_bitcmp1 from the byte offset), the child's offset one s_lshl1_add_u32;
+//   * descend and skip are two short tails instead of eight computed candidates and four selects.
+// 36-39 instructions per step instead of 61.  The opening test is !(width^2 >= theta^2 d^2): for numbers the reference's
+// `<`, for a NaN distance "accept" — a walk cannot descend below the body level whatever the state holds.
+// Hazards are handled by hand inside the block (gfx940 rules: a transcendental's result needs one instruction before its
+// first use, an SGPR written by a VALU instruction two before a VALU instruction reads it; SALU readers interlock).
+// The record lives in s[64:79] (fields are addressed as sub-ranges, which an asm operand cannot express).
+// ------------------------------------------------------------------------------------------------
+#define K9_COUNT_A                                                                                                        \
+  "s_cmp_eq_u32 %[spm1], 31\n\t"                                                                                          \
+  "s_cbranch_scc1 .LK9cb%=\n\t"                                                                                              \
+  "v_add_u32_e32 %[cn], 1, %[cn]\n\t"                                                                                     \
+  "s_branch .LK9cc%=\n"                                                                                                      \
+  ".LK9cb%=:\n\t"                                                                                                            \
+  "s_lshr_b32 %[t1], %[cur], 5\n\t"                                                                                       \
+  "v_cmp_ne_u32_e32 vcc, %[t1], %[bi]\n\t"                                                                                \
+  "s_not_b32 %[t2], %[t1]\n\t"                                                                                            \
+  "s_and_b32 %[t2], %[t2], 1\n\t"                                                                                         \
+  "v_addc_co_u32_e32 %[cb], vcc, 0, %[cb], vcc\n\t"                                                                       \
+  "v_add_u32_e32 %[cl], %[t2], %[cl]\n"                                                                                   \
+  ".LK9cc%=:\n\t"
+#define K9_COUNT_B                                                                                                        \
+  "s_cmp_lg_u32 %[spm1], 31\n\t"                                                                                          \
+  "s_cselect_b32 %[t1], 1, 0\n\t"                                                                                         \
+  "v_add_u32_e32 %[cm], %[t1], %[cm]\n\t"
+
+// the accepted term's weight for r2 >= 2^-16 (pair_math<double>::weight_far, same operations in the same order)
+#define K9_FAR(RM)                                                                                                        \
+  "v_mul_f64 %[y2], %[y], %[y]\n\t"                                                                                       \
+  "v_fma_f64 %[e], -%[r2], %[y2], 1.0\n\t"                                                                                \
+  "v_mul_f64 %[y], %[y], %[y2]\n\t"                                                                                       \
+  "v_fma_f64 %[p], %[k1875], %[e], %[k15]\n\t"                                                                            \
+  "v_ldexp_f64 %[q], -%[y], %[m52]\n\t"                                                                                   \
+  "v_mul_f64 %[y], %[y], " RM "\n\t"                                                                                      \
+  "v_fmac_f64_e32 %[q], %[p], %[e]\n\t"                                                                                   \
+  "v_fmac_f64_e32 %[y], %[y], %[q]\n\t"
+
+// Z(...) keeps its argument for D = 3 and drops it for D = 2; RM / RW2 are the record's mass and width^2 register pairs,
+// RW2HI the high word of the latter.
+#define K9_ISA_TEXT(Z, RM, RW2, RW2HI, CNT_A, CNT_B)                                                                            \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc0 .LK9end%=\n"                                                                                               \
+  ".LK9top%=:\n\t"                                                                                                           \
+  "s_load_dwordx16 s[64:79], %[node], %[off]\n\t"                                                                         \
+  "v_cmpx_eq_u32_e64 %[match], %[cur], %[key]\n\t"                                                                        \
+  "s_bitcmp1_b32 %[off], 6\n\t"                                                                                           \
+  "s_addc_u32 %[ka], %[cur], %[spm1]\n\t"                                                                                 \
+  CNT_A                                                                                                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
+  "v_add_f64 %[d0], %[xs0], -s[64:65]\n\t"                                                                                \
+  "v_add_f64 %[d1], %[xs1], -s[66:67]\n\t"                                                                                \
+  Z("v_add_f64 %[d2], %[xs2], -s[68:69]\n\t")                                                                             \
+  "v_mul_f64 %[r2], %[d0], %[d0]\n\t"                                                                                     \
+  "v_mul_f64 %[t], %[d1], %[d1]\n\t"                                                                                      \
+  "v_add_f64 %[r2], %[r2], %[t]\n\t"                                                                                      \
+  Z("v_mul_f64 %[t], %[d2], %[d2]\n\t"                                                                                    \
+    "v_add_f64 %[r2], %[r2], %[t]\n\t")                                                                                   \
+  "v_mul_f64 %[t], %[th2], %[r2]\n\t"                                                                                     \
+  "v_cmpx_nge_f64_e64 %[take], " RW2 ", %[t]\n\t"                                                                         \
+  "s_cbranch_execz .LK9notake%=\n\t"                                                                                         \
+  "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
+  "v_mov_b32_e32 %[key], %[ka]\n\t"                                                                                       \
+  CNT_B                                                                                                                   \
+  "s_cmp_lt_i32 " RW2HI ", %[khi]\n\t" /* a body record (width^2 = -1) or a node so small that an accepted d2 can be < 2^-16 */ \
+  "s_cbranch_scc1 .LK9maybe%=\n"                                                                                             \
+  ".LK9far%=:\n\t"                                                                                                           \
+  K9_FAR(RM)                                                                                                              \
+  ".LK9acc%=:\n\t"                                                                                                           \
+  "v_fma_f64 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
+  "v_fma_f64 %[acc1], -%[y], %[d1], %[acc1]\n\t"                                                                          \
+  Z("v_fma_f64 %[acc2], -%[y], %[d2], %[acc2]\n")                                                                         \
+  ".LK9notake%=:\n\t"                                                                                                        \
+  "s_andn2_b64 exec, %[match], %[take]\n\t"                                                                               \
+  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                            \
+  "v_add_u32_e32 %[key], 1, %[key]\n\t"                                                                                   \
+  "s_add_i32 %[cur], %[cur], 1\n\t"                                                                                       \
+  "s_lshl1_add_u32 %[off], %[off], 64\n\t"                                                                                \
+  "s_lshr_b32 %[spm1], %[spm1], 1\n\t"                                                                                    \
+  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
+  "s_branch .LK9top%=\n"                                                                                                     \
+  ".LK9skip%=:\n\t"                                                                                                          \
+  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
+  "v_cmp_gt_u32_e64 %[wt], %[ka], %[key]\n\t"                                                                             \
+  "s_lshr_b32 %[t1], %[off], 1\n\t"                                                                                       \
+  "s_add_i32 %[t2], %[off], 64\n\t"                                                                                       \
+  "s_lshl1_add_u32 %[t3], %[spm1], 1\n\t"                                                                                 \
+  "s_bitcmp1_b32 %[off], 6\n\t"                                                                                           \
+  "s_cselect_b32 %[off], %[t2], %[t1]\n\t"                                                                                \
+  "s_cselect_b32 %[spm1], %[spm1], %[t3]\n\t"                                                                             \
+  "s_mov_b32 %[cur], %[ka]\n\t"                                                                                           \
+  "s_cmp_lg_u64 %[wt], 0\n\t"                                                                                             \
+  "s_cbranch_scc1 .LK9jump%=\n"                                                                                              \
+  ".LK9chk%=:\n\t"                                                                                                           \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                             \
+  "s_branch .LK9end%=\n"                                                                                                     \
+  ".LK9maybe%=:\n\t"                                                                                                         \
+  "v_cmp_gt_u64_e64 %[near], %[nearhi], %[r2]\n\t"                                                                        \
+  "s_cmp_eq_u64 %[near], 0\n\t"                                                                                           \
+  "s_cbranch_scc1 .LK9far%=\n\t"                                                                                             \
+  K9_FAR(RM) /* some accepted entry is closer than 2^-8: those lanes take the guarded form (pair_math::weight<3>) */      \
+  "s_mov_b64 %[wt], exec\n\t"                                                                                             \
+  "s_mov_b64 exec, %[near]\n\t"                                                                                           \
+  "v_mov_b64_e32 %[r2], %[tiny]\n\t"                                                                                      \
+  "v_fmac_f64_e32 %[r2], %[d0], %[d0]\n\t"                                                                                \
+  "v_fmac_f64_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
+  Z("v_fmac_f64_e32 %[r2], %[d2], %[d2]\n\t")                                                                             \
+  "v_rsq_f64_e32 %[y2], %[r2]\n\t"                                                                                        \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_mul_f64 %[e], %[r2], %[y2]\n\t"                                                                                      \
+  "v_fma_f64 %[y2], -%[e], %[y2], 1.0\n\t"                                                                                \
+  "v_fma_f64 %[p], %[y2], %[k0375], 0.5\n\t"                                                                              \
+  "v_mul_f64 %[y2], %[e], %[y2]\n\t"                                                                                      \
+  "v_fmac_f64_e32 %[e], %[y2], %[p]\n\t"                                                                                  \
+  "v_fma_f64 %[r2], %[r2], %[e], %[eps]\n\t"                                                                              \
+  "v_rcp_f64_e32 %[y2], %[r2]\n\t"                                                                                        \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_fma_f64 %[r2], -%[r2], %[y2], 1.0\n\t"                                                                               \
+  "v_mul_f64 %[y2], %[y2], " RM "\n\t"                                                                                    \
+  "v_fmac_f64_e32 %[r2], %[r2], %[r2]\n\t"                                                                                \
+  "v_fma_f64 %[y], %[y2], %[r2], %[y2]\n\t"                                                                               \
+  "s_mov_b64 exec, %[wt]\n\t"                                                                                             \
+  "s_branch .LK9acc%=\n"                                                                                                     \
+  ".LK9jump%=:\n\t" /* lanes wait below the entry just left: continue at the smallest key any lane holds */                  \
+  "s_mov_b64 vcc, %[wt]\n"                                                                                                \
+  ".LK9j1%=:\n\t"                                                                                                            \
+  "s_ff1_i32_b64 %[t1], vcc\n\t"                                                                                          \
+  "v_readlane_b32 %[cur], %[key], %[t1]\n\t"                                                                              \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_cmp_gt_u32_e32 vcc, %[cur], %[key]\n\t"                                                                              \
+  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                             \
+  "s_and_b32 %[t1], %[cur], 31\n\t"                                                                                       \
+  "s_sub_i32 %[t1], %[nlev], %[t1]\n\t"                                                                                   \
+  "s_lshl_b32 %[t2], -1, %[cur]\n\t"                                                                                      \
+  "s_not_b32 %[t2], %[t2]\n\t"                                                                                            \
+  "s_lshr_b32 %[t3], %[cur], 5\n\t"                                                                                       \
+  "s_lshr_b32 %[t3], %[t3], %[t1]\n\t"                                                                                    \
+  "s_add_i32 %[t3], %[t3], %[t2]\n\t"                                                                                     \
+  "s_lshl_b32 %[off], %[t3], 6\n\t"                                                                                       \
+  "s_lshl_b32 %[spm1], 32, %[t1]\n\t"                                                                                     \
+  "s_add_i32 %[spm1], %[spm1], -1\n\t"                                                                                    \
+  "s_branch .LK9chk%=\n"                                                                                                     \
+  ".LK9end%=:\n\t"                                                                                                           \
+  "s_mov_b64 exec, %[sv]"
+#define K9_KEEP(...) __VA_ARGS__
+#define K9_DROP(...) ""
+
+template <int D, bool COUNT>
+__global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<double>* __restrict__ node, double* __restrict__ a,
+                                                                 const double* __restrict__ x, double c, uint32_t sz, uint32_t first,
+                                                                 uint32_t count, double theta2, uint32_t nlevels,
+                                                                 uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
+                                                                 const uint32_t* __restrict__ nitems, uint32_t stride) {
+  static_assert(sizeof(tree_rec<double>) == 64, "the step program addresses 64-byte records");
+  // work item of this block, as in bvh_force_wave_kernel
+  uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
+  if (items) {
+    const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
+    if (slot >= nitems[xcd]) return;
+    const uint32_t it = items[xcd * stride + slot];
+    group   = it & 0xfffffu;
+    lane_lo = (it >> 20) & 63u;
+    lane_hi = it >> 26;
+  }
+  const uint32_t local = group * 64u + threadIdx.x;
+  const bool valid     = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
+  const uint32_t bi    = first + (valid ? local : 0u);
+  uint32_t key         = valid ? 0u : 0xffffffffu;
+  double xs[3] = {0.0, 0.0, 0.0}, acc[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < D; ++k) xs[k] = x[uint64_t(bi) * D + k];
+  uint32_t cn = 0, cl = 0, cm = 0, cb = 0;
+  uint32_t cur = 0, off = 0, spm1 = (32u << nlevels) - 1u;
+  const uint32_t endk = (sz << 5) - 1u;  // see bvh_force_wave_kernel
+  const pair_consts<double> pc;
+  double k0375 = 0.375, tiny = pair_math<double>::tiny, eps = DBL_EPSILON;
+  uint64_t nearhi = uint64_t(pair_math<double>::near_hi) << 32;
+  int m52 = -52;
+  // An accepted entry satisfies width^2 < fl(theta^2 d2); with d2 < 2^-16 that is <= theta^2 * 2^-16 (exact scaling), so only
+  // records whose width^2 has a high word <= that bound's — and body records, width^2 = -1, negative as an integer — can hold
+  // a near pair: a scalar compare decides whether the wave looks at all.
+  int khi, khi_v = int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1;
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(khi) : "v"(khi_v));  // (the product is computed by the vector unit)
+  asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
+  double d0, d1, d2, r2, t, y, y2, e, p, q;
+  uint32_t ka, t1, t2, t3;
+  uint64_t match, take, near, wt, sv;
+#define K9_OPERANDS                                                                                                        \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
+    [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
+    [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q),    \
+    [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take),              \
+    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv)                                                                     \
+  : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi), \
+    [k0375] "s"(k0375), [m52] "s"(m52), [khi] "s"(khi), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
+    [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
+  : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
+  if constexpr (D == 3) {
+    if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+    else asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", "", "") K9_OPERANDS);
+  } else {
+    if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+    else asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", "", "") K9_OPERANDS);
+  }
+#undef K9_OPERANDS
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(bi) * 4 + 0] = cn;
+      counters[uint64_t(bi) * 4 + 1] = cl;
+      counters[uint64_t(bi) * 4 + 2] = cm;
+      counters[uint64_t(bi) * 4 + 3] = cb;
     }
   }
 }
@@ -903,9 +1138,10 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
   // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
-  // 256 CUs (ms per whole bvh step over 200 steps, sweep / per-lane): f64 1.55 / 1.25 at 10^5, 1.85 / 1.80 at 1.5*10^5, 2.25 / 2.55
-  // at 2*10^5, 2.65 / 3.9 at 3*10^5; f32 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.
-  const uint32_t crossover = sizeof(T) == 8 ? 160000u : 250000u;
+  // 256 CUs (ms per whole bvh step over 200 steps, sweep / per-lane): f64 (hand-scheduled sweep) 1.15 / 1.0 at 6*10^4, 1.4 / 1.25
+  // at 10^5, 1.5 / 1.5 at 1.3*10^5, 1.65 / 1.85 at 1.6*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1 at 5*10^5; f32 (compiler-scheduled)
+  // 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.
+  const uint32_t crossover = sizeof(T) == 8 ? 130000u : 250000u;
   int traversal = t->traversal;
   if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
@@ -917,6 +1153,13 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
   // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
   const int bpl            = traversal == 4 ? 2 : 1;
+  // f64: the step program written out as ISA (bvh_force_sweep_isa_kernel) is the sweep that auto and 2 select; 5 forces it, 3 keeps
+  // the compiler-scheduled form (f32 always).  All forms are bitwise identical.
+  const bool isa = sizeof(T) == 8 && wave && (traversal == 0 || traversal == 2 || traversal == 5);
+  if (traversal == 5 && sizeof(T) != 8) {
+    set_error("traversal 5 (hand-scheduled sweep) exists for double precision only");
+    return NBODY_ERR_ARG;
+  }
   const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
   const uint32_t blocks    = (s->count + per_block - 1) / per_block;
 #define NB_ARGS                                                                                                   \
@@ -945,6 +1188,11 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   if (wave && bpl == 2) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
+  } else if (wave && isa) {
+    if constexpr (sizeof(T) == 8) {
+      if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<D, true>), NB_WARGS);
+      else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<D, false>), NB_WARGS);
+    }
   } else if (wave) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
@@ -1048,7 +1296,7 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
 
 extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
-  NB_ARG(mode >= 0 && mode <= 4, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (wave-cooperative with 1 / 2 bodies per lane), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 5, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep, double only), got %d", mode);
   t->traversal = mode;
   return NBODY_OK;
 }

@@ -95,16 +95,20 @@ def test_bvh_randomized_systems_bit_exact(nb, oracle):
         dtype, dim = int(rng.integers(0, 2)), int(rng.integers(2, 4))
         n = int(rng.integers(2, 3000))
         theta = float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.4]))
-        _phases(nb, oracle, dtype, dim, None, n, theta, counts=True, traversal=(1, 3, 4)[case % 3],
+        modes = (1, 3, 4, 5, 2) if dtype == 1 else (1, 3, 4)  # 5 / 2: the hand-scheduled sweep (double only)
+        _phases(nb, oracle, dtype, dim, None, n, theta, counts=True, traversal=modes[case % len(modes)],
                 system=_random_system(nb, oracle, rng, dtype, dim, n))
 
 
 @pytest.mark.parametrize("dtype", [1, 0])
 def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
     """K9's two scheduling forms perform the same per-lane arithmetic in the same order."""
-    for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0)):
+    # the last two: theta so large that bodies accept the ROOT, at sizes that are powers of two (the sweep's end key)
+    for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0),
+                              (3, "uniform", 4096, 3.0), (2, "galaxy", 64, 2.5)):
         res = []
-        for mode in (1, 3, 4):  # per-lane walks; sweep with 1 and with 2 bodies per lane
+        # per-lane walks; compiler-scheduled sweep with 1 and with 2 bodies per lane; the sweep written as ISA (double only)
+        for mode in (1, 3, 4) + ((5,) if dtype == 1 else ()):
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.bvh.set_traversal(mode)
             dev.bvh.enable_counters(True)
@@ -228,7 +232,7 @@ def test_sweep_work_items_and_shard_windows(nb):
     t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
     t.enable_counters(True)
     res = {}
-    for mode, env in ((1, None), (3, None), (3, "0"), (4, None)):
+    for mode, env in ((1, None), (3, None), (3, "0"), (4, None), (5, None), (5, "0")):
         if env is not None:
             os.environ["NBODY_K9_ORDER"] = env
         try:
@@ -241,9 +245,10 @@ def test_sweep_work_items_and_shard_windows(nb):
     base = res[(1, None)]
     for k, r in res.items():
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), k
-    t.set_traversal(3)
-    for first, count in ((0, 70000), (70000, 65539), (135539, n - 135539)):
-        w = dev.state(first, count)
-        t.compute_force(w, 0.5, dev.stream)
-    dev.sync()
-    assert np.array_equal(dev.download().a, base[0])
+    for mode in (3, 5):
+        t.set_traversal(mode)
+        for first, count in ((0, 70000), (70000, 65539), (135539, n - 135539)):
+            w = dev.state(first, count)
+            t.compute_force(w, 0.5, dev.stream)
+        dev.sync()
+        assert np.array_equal(dev.download().a, base[0]), mode

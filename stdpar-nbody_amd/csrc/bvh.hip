@@ -850,41 +850,40 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
 // ------------------------------------------------------------------------------------------------
 #define K9_COUNT_A                                                                                                        \
   "s_cmp_eq_u32 %[spm1], 31\n\t"                                                                                          \
-  "s_cbranch_scc1 .LK9cb%=\n\t"                                                                                              \
+  "s_cbranch_scc1 .LK9cb%=\n\t"                                                                                           \
   "v_add_u32_e32 %[cn], 1, %[cn]\n\t"                                                                                     \
-  "s_branch .LK9cc%=\n"                                                                                                      \
-  ".LK9cb%=:\n\t"                                                                                                            \
+  "s_mov_b32 %[cinc], 1\n\t"                                                                                              \
+  "s_branch .LK9cc%=\n"                                                                                                   \
+  ".LK9cb%=:\n\t"                                                                                                         \
   "s_lshr_b32 %[t1], %[cur], 5\n\t"                                                                                       \
   "v_cmp_ne_u32_e32 vcc, %[t1], %[bi]\n\t"                                                                                \
   "s_not_b32 %[t2], %[t1]\n\t"                                                                                            \
   "s_and_b32 %[t2], %[t2], 1\n\t"                                                                                         \
   "v_addc_co_u32_e32 %[cb], vcc, 0, %[cb], vcc\n\t"                                                                       \
-  "v_add_u32_e32 %[cl], %[t2], %[cl]\n"                                                                                   \
+  "v_add_u32_e32 %[cl], %[t2], %[cl]\n\t"                                                                                 \
+  "s_mov_b32 %[cinc], 0\n"                                                                                                \
   ".LK9cc%=:\n\t"
-#define K9_COUNT_B                                                                                                        \
-  "s_cmp_lg_u32 %[spm1], 31\n\t"                                                                                          \
-  "s_cselect_b32 %[t1], 1, 0\n\t"                                                                                         \
-  "v_add_u32_e32 %[cm], %[t1], %[cm]\n\t"
+#define K9_COUNT_B "v_add_u32_e32 %[cm], %[cinc], %[cm]\n\t"
 
-// the accepted term's weight for r2 >= 2^-16 (pair_math<double>::weight_far, same operations in the same order)
-#define K9_FAR(RM)                                                                                                        \
+// the accepted term's weight for r2 >= 2^-16 (pair_math<double>::weight_far, same operations in the same order); %[ms] = mass
+#define K9_FAR                                                                                                            \
   "v_mul_f64 %[y2], %[y], %[y]\n\t"                                                                                       \
   "v_fma_f64 %[e], -%[r2], %[y2], 1.0\n\t"                                                                                \
   "v_mul_f64 %[y], %[y], %[y2]\n\t"                                                                                       \
   "v_fma_f64 %[p], %[k1875], %[e], %[k15]\n\t"                                                                            \
   "v_ldexp_f64 %[q], -%[y], %[m52]\n\t"                                                                                   \
-  "v_mul_f64 %[y], %[y], " RM "\n\t"                                                                                      \
+  "v_mul_f64 %[y], %[y], %[ms]\n\t"                                                                                       \
   "v_fmac_f64_e32 %[q], %[p], %[e]\n\t"                                                                                   \
   "v_fmac_f64_e32 %[y], %[y], %[q]\n\t"
 
 // Z(...) keeps its argument for D = 3 and drops it for D = 2; RM / RW2 are the record's mass and width^2 register pairs,
 // RW2HI the high word of the latter.
-#define K9_ISA_TEXT(Z, RM, RW2, RW2HI, CNT_A, CNT_B)                                                                            \
+#define K9_ISA_TEXT(Z, RM, RW2, RW2HI, CNT_A, CNT_B)                                                                      \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
   "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc0 .LK9end%=\n"                                                                                               \
-  ".LK9top%=:\n\t"                                                                                                           \
-  "s_load_dwordx16 s[64:79], %[node], %[off]\n\t"                                                                         \
+  "s_cbranch_scc0 .LK9end%=\n\t"                                                                                          \
+  "s_load_dwordx16 s[64:79], %[node], %[off]\n"                                                                           \
+  ".LK9top%=:\n\t"                                                                                                        \
   "v_cmpx_eq_u32_e64 %[match], %[cur], %[key]\n\t"                                                                        \
   "s_bitcmp1_b32 %[off], 6\n\t"                                                                                           \
   "s_addc_u32 %[ka], %[cur], %[spm1]\n\t"                                                                                 \
@@ -900,28 +899,36 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     "v_add_f64 %[r2], %[r2], %[t]\n\t")                                                                                   \
   "v_mul_f64 %[t], %[th2], %[r2]\n\t"                                                                                     \
   "v_cmpx_nge_f64_e64 %[take], " RW2 ", %[t]\n\t"                                                                         \
-  "s_cbranch_execz .LK9notake%=\n\t"                                                                                         \
-  "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
+  /* the decision is made: move the lanes and the sweep, request the NEXT record, and only then evaluate this one */      \
   "v_mov_b32_e32 %[key], %[ka]\n\t"                                                                                       \
-  CNT_B                                                                                                                   \
-  "s_cmp_lt_i32 " RW2HI ", %[khi]\n\t" /* a body record (width^2 = -1) or a node so small that an accepted d2 can be < 2^-16 */ \
-  "s_cbranch_scc1 .LK9maybe%=\n"                                                                                             \
-  ".LK9far%=:\n\t"                                                                                                           \
-  K9_FAR(RM)                                                                                                              \
-  ".LK9acc%=:\n\t"                                                                                                           \
-  "v_fma_f64 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
-  "v_fma_f64 %[acc1], -%[y], %[d1], %[acc1]\n\t"                                                                          \
-  Z("v_fma_f64 %[acc2], -%[y], %[d2], %[acc2]\n")                                                                         \
-  ".LK9notake%=:\n\t"                                                                                                        \
+  "s_mov_b64 %[ms], " RM "\n\t"                                                                                           \
+  "s_mov_b32 %[w2s], " RW2HI "\n\t"                                                                                       \
   "s_andn2_b64 exec, %[match], %[take]\n\t"                                                                               \
-  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                            \
+  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                         \
   "v_add_u32_e32 %[key], 1, %[key]\n\t"                                                                                   \
   "s_add_i32 %[cur], %[cur], 1\n\t"                                                                                       \
   "s_lshl1_add_u32 %[off], %[off], 64\n\t"                                                                                \
-  "s_lshr_b32 %[spm1], %[spm1], 1\n\t"                                                                                    \
+  "s_lshr_b32 %[spm1], %[spm1], 1\n"                                                                                      \
+  ".LK9load%=:\n\t"                                                                                                       \
+  "s_load_dwordx16 s[64:79], %[node], %[off]\n"                                                                           \
+  ".LK9eval%=:\n\t"                                                                                                       \
+  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
+  "s_cbranch_scc0 .LK9next%=\n\t"                                                                                         \
+  "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
+  CNT_B                                                                                                                   \
+  "s_cmp_lt_i32 %[w2s], %[khi]\n\t" /* a body record (width^2 = -1) or a node so small that an accepted d2 can be < 2^-16 */\
+  "s_cbranch_scc1 .LK9maybe%=\n"                                                                                          \
+  ".LK9far%=:\n\t"                                                                                                        \
+  K9_FAR                                                                                                                  \
+  ".LK9acc%=:\n\t"                                                                                                        \
+  "v_fma_f64 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
+  "v_fma_f64 %[acc1], -%[y], %[d1], %[acc1]\n" Z("\t" "v_fma_f64 %[acc2], -%[y], %[d2], %[acc2]\n")                       \
+  ".LK9next%=:\n\t"                                                                                                       \
   "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
-  "s_branch .LK9top%=\n"                                                                                                     \
-  ".LK9skip%=:\n\t"                                                                                                          \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                          \
+  "s_branch .LK9end%=\n"                                                                                                  \
+  ".LK9skip%=:\n\t"                                                                                                       \
   "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
   "v_cmp_gt_u32_e64 %[wt], %[ka], %[key]\n\t"                                                                             \
   "s_lshr_b32 %[t1], %[off], 1\n\t"                                                                                       \
@@ -932,16 +939,16 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   "s_cselect_b32 %[spm1], %[spm1], %[t3]\n\t"                                                                             \
   "s_mov_b32 %[cur], %[ka]\n\t"                                                                                           \
   "s_cmp_lg_u64 %[wt], 0\n\t"                                                                                             \
-  "s_cbranch_scc1 .LK9jump%=\n"                                                                                              \
-  ".LK9chk%=:\n\t"                                                                                                           \
+  "s_cbranch_scc1 .LK9jump%=\n"                                                                                           \
+  ".LK9chk%=:\n\t"                                                                                                        \
   "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                             \
-  "s_branch .LK9end%=\n"                                                                                                     \
-  ".LK9maybe%=:\n\t"                                                                                                         \
+  "s_cbranch_scc1 .LK9load%=\n\t"                                                                                         \
+  "s_branch .LK9eval%=\n"                                                                                                 \
+  ".LK9maybe%=:\n\t"                                                                                                      \
   "v_cmp_gt_u64_e64 %[near], %[nearhi], %[r2]\n\t"                                                                        \
   "s_cmp_eq_u64 %[near], 0\n\t"                                                                                           \
-  "s_cbranch_scc1 .LK9far%=\n\t"                                                                                             \
-  K9_FAR(RM) /* some accepted entry is closer than 2^-8: those lanes take the guarded form (pair_math::weight<3>) */      \
+  "s_cbranch_scc1 .LK9far%=\n\t"                                                                                          \
+  K9_FAR /* some accepted entry is closer than 2^-8: those lanes take the guarded form (pair_math::weight<3>) */          \
   "s_mov_b64 %[wt], exec\n\t"                                                                                             \
   "s_mov_b64 exec, %[near]\n\t"                                                                                           \
   "v_mov_b64_e32 %[r2], %[tiny]\n\t"                                                                                      \
@@ -959,19 +966,19 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   "v_rcp_f64_e32 %[y2], %[r2]\n\t"                                                                                        \
   "s_nop 0\n\t"                                                                                                           \
   "v_fma_f64 %[r2], -%[r2], %[y2], 1.0\n\t"                                                                               \
-  "v_mul_f64 %[y2], %[y2], " RM "\n\t"                                                                                    \
+  "v_mul_f64 %[y2], %[y2], %[ms]\n\t"                                                                                     \
   "v_fmac_f64_e32 %[r2], %[r2], %[r2]\n\t"                                                                                \
   "v_fma_f64 %[y], %[y2], %[r2], %[y2]\n\t"                                                                               \
   "s_mov_b64 exec, %[wt]\n\t"                                                                                             \
-  "s_branch .LK9acc%=\n"                                                                                                     \
-  ".LK9jump%=:\n\t" /* lanes wait below the entry just left: continue at the smallest key any lane holds */                  \
+  "s_branch .LK9acc%=\n"                                                                                                  \
+  ".LK9jump%=:\n\t" /* lanes wait below the entry just left: continue at the smallest key any lane holds */               \
   "s_mov_b64 vcc, %[wt]\n"                                                                                                \
-  ".LK9j1%=:\n\t"                                                                                                            \
+  ".LK9j1%=:\n\t"                                                                                                         \
   "s_ff1_i32_b64 %[t1], vcc\n\t"                                                                                          \
   "v_readlane_b32 %[cur], %[key], %[t1]\n\t"                                                                              \
   "s_nop 1\n\t"                                                                                                           \
   "v_cmp_gt_u32_e32 vcc, %[cur], %[key]\n\t"                                                                              \
-  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                             \
+  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                          \
   "s_and_b32 %[t1], %[cur], 31\n\t"                                                                                       \
   "s_sub_i32 %[t1], %[nlev], %[t1]\n\t"                                                                                   \
   "s_lshl_b32 %[t2], -1, %[cur]\n\t"                                                                                      \
@@ -982,8 +989,8 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   "s_lshl_b32 %[off], %[t3], 6\n\t"                                                                                       \
   "s_lshl_b32 %[spm1], 32, %[t1]\n\t"                                                                                     \
   "s_add_i32 %[spm1], %[spm1], -1\n\t"                                                                                    \
-  "s_branch .LK9chk%=\n"                                                                                                     \
-  ".LK9end%=:\n\t"                                                                                                           \
+  "s_branch .LK9chk%=\n"                                                                                                  \
+  ".LK9end%=:\n\t"                                                                                                        \
   "s_mov_b64 exec, %[sv]"
 #define K9_KEEP(...) __VA_ARGS__
 #define K9_DROP(...) ""
@@ -1026,14 +1033,15 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(khi) : "v"(khi_v));  // (the product is computed by the vector unit)
   asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
   double d0, d1, d2, r2, t, y, y2, e, p, q;
-  uint32_t ka, t1, t2, t3;
+  uint32_t ka, t1, t2, t3, w2s, cinc;
   uint64_t match, take, near, wt, sv;
+  double ms;
 #define K9_OPERANDS                                                                                                        \
   : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
     [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
     [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q),    \
     [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take),              \
-    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv)                                                                     \
+    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms), [w2s] "=&s"(w2s), [cinc] "=&s"(cinc)                                                                     \
   : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi), \
     [k0375] "s"(k0375), [m52] "s"(m52), [khi] "s"(khi), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
     [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
@@ -1182,8 +1190,10 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     items  = t->order;
     nitems = t->order_n;
   }
+  const char* le = getenv("NBODY_K9_LDS");  // experiments: dynamic LDS bytes per block, to cap the waves per SIMD
+  const uint32_t lds = le ? uint32_t(atoi(le)) : 0u;
 #define NB_WARGS                                                                                                             \
-  dim3(wave_blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
+  dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
    s->first, s->count, th2, t->nlevels, t->counters, items, nitems, stride
   if (wave && bpl == 2) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);

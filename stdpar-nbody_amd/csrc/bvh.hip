@@ -1146,10 +1146,12 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
   // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
-  // 256 CUs (ms per whole bvh step over 200 steps, sweep / per-lane): f64 (hand-scheduled sweep) 1.15 / 1.0 at 6*10^4, 1.4 / 1.25
-  // at 10^5, 1.5 / 1.5 at 1.3*10^5, 1.65 / 1.85 at 1.6*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1 at 5*10^5; f32 (compiler-scheduled)
-  // 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.
-  const uint32_t crossover = sizeof(T) == 8 ? 130000u : 250000u;
+  // 256 CUs (ms per whole bvh step over the first 200 steps of the galaxy, sweep / per-lane): f64 (hand-scheduled sweep) 0.90 / 0.85
+  // at 4*10^4, 1.0 / 1.0 at 6*10^4, 1.1 / 1.15 at 8*10^4, 1.2 / 1.25 at 10^5, 1.3 / 1.5 at 1.3*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1
+  // at 5*10^5; f32 (compiler-scheduled) 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.  A system that has
+  // evolved favours the sweep further: escapers inflate the box, walks get 3x longer and the per-lane form's divergent
+  // gathers pay for every entry (10^5 bodies after 400-1000 steps: sweep 1.7-2.1 ms, per-lane 3.0-3.7 ms per traversal).
+  const uint32_t crossover = sizeof(T) == 8 ? 50000u : 250000u;
   int traversal = t->traversal;
   if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);

@@ -252,3 +252,34 @@ def test_sweep_work_items_and_shard_windows(nb):
             t.compute_force(w, 0.5, dev.stream)
         dev.sync()
         assert np.array_equal(dev.download().a, base[0]), mode
+
+
+def test_traversal_terminates_on_nan_and_inf_positions():
+    """A state that holds NaN or infinite positions (a run that blew up) must not send a walk below the body level: the
+    opening test is !(width^2 >= theta^2 d^2), body records carry width^2 = -1, so every form terminates at the bodies at the
+    latest.  Run in a child process with a time limit (a walk that left the tree would fault or never end)."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r)
+        from conftest import load_package
+        nb = load_package()
+        for bad in (np.nan, np.inf, -np.inf):
+            for dtype in (1, 0):
+                for mode in (1, 3) + ((5,) if dtype == 1 else ()):
+                    hs = nb.build_model(dtype, 3, "galaxy", 5000)
+                    hs.x[17, 0] = bad; hs.x[4000, 2] = bad; hs.x[4999] = bad
+                    dev = nb.DeviceSystem.from_host(hs)
+                    dev.bvh.set_traversal(mode)
+                    for _ in range(2):
+                        dev.bvh_force(0.5)
+                        dev.accelerate_step()
+                    dev.sync()
+                    out = dev.download()
+                    assert out.a.shape == hs.a.shape
+                    dev.close()
+        print("terminated")
+    """ % os.path.join(root, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "terminated" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -150,9 +150,8 @@ int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* s
 int nbody_bvh_enable_counters(nbody_bvh* t, int on);
 /* K9 scheduling form: 0 = auto, 1 = one independent stackless walk per lane (the reference's loop as is),
  * 2 = wave-cooperative sweep of the union of the wave's walks in DFS key order (3 / 4: the compiler-scheduled step
- * program with 1 / 2 bodies per lane; 5: the step program written out as ISA, double precision only — what 0 and 2
- * use for double).  All forms make every body perform the same tests in the same order: results and counters are
- * bitwise identical. */
+ * program with 1 / 2 bodies per lane; 5: the step program written out as ISA — what 0 and 2 use).  All forms make
+ * every body perform the same tests in the same order: results and counters are bitwise identical. */
 int nbody_bvh_set_traversal(nbody_bvh* t, int mode);
 uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
 

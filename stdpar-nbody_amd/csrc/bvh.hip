@@ -992,16 +992,107 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
   "s_branch .LK9chk%=\n"                                                                                                  \
   ".LK9end%=:\n\t"                                                                                                        \
   "s_mov_b64 exec, %[sv]"
+// The same step program for single precision: 32-byte records in s[64:71] (off counts 32-byte units), the opening test on the
+// unfused d2 as in dist2_ref, the accepted term as pair_math<float>::weight on the fused r2 (no near path: 1-ulp seeds).
+#define K9_ISA_TEXT_F32(Z, RM, RW2, CNT_A, CNT_B)                                                                         \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc0 .LK9end%=\n\t"                                                                                          \
+  "s_load_dwordx8 s[64:71], %[node], %[off]\n"                                                                            \
+  ".LK9top%=:\n\t"                                                                                                        \
+  "v_cmpx_eq_u32_e64 %[match], %[cur], %[key]\n\t"                                                                        \
+  "s_bitcmp1_b32 %[off], 5\n\t"                                                                                           \
+  "s_addc_u32 %[ka], %[cur], %[spm1]\n\t"                                                                                 \
+  CNT_A                                                                                                                   \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
+  "v_subrev_f32_e32 %[d0], s64, %[xs0]\n\t"                                                                               \
+  "v_subrev_f32_e32 %[d1], s65, %[xs1]\n\t"                                                                               \
+  Z("v_subrev_f32_e32 %[d2], s66, %[xs2]\n\t")                                                                            \
+  "v_mul_f32_e32 %[r2], %[d0], %[d0]\n\t"                                                                                 \
+  "v_mul_f32_e32 %[t], %[d1], %[d1]\n\t"                                                                                  \
+  "v_add_f32_e32 %[r2], %[r2], %[t]\n\t"                                                                                  \
+  Z("v_mul_f32_e32 %[t], %[d2], %[d2]\n\t"                                                                                \
+    "v_add_f32_e32 %[r2], %[r2], %[t]\n\t")                                                                               \
+  "v_mul_f32_e32 %[t], %[th2], %[r2]\n\t"                                                                                 \
+  "v_cmpx_nge_f32_e64 %[take], " RW2 ", %[t]\n\t"                                                                         \
+  "v_mov_b32_e32 %[key], %[ka]\n\t"                                                                                       \
+  "s_mov_b32 %[ms], " RM "\n\t"                                                                                           \
+  "s_andn2_b64 exec, %[match], %[take]\n\t"                                                                               \
+  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                         \
+  "v_add_u32_e32 %[key], 1, %[key]\n\t"                                                                                   \
+  "s_add_i32 %[cur], %[cur], 1\n\t"                                                                                       \
+  "s_lshl1_add_u32 %[off], %[off], 32\n\t"                                                                                \
+  "s_lshr_b32 %[spm1], %[spm1], 1\n"                                                                                      \
+  ".LK9load%=:\n\t"                                                                                                       \
+  "s_load_dwordx8 s[64:71], %[node], %[off]\n"                                                                            \
+  ".LK9eval%=:\n\t"                                                                                                       \
+  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
+  "s_cbranch_scc0 .LK9next%=\n\t"                                                                                         \
+  "v_fma_f32 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
+  "v_fmac_f32_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
+  Z("v_fmac_f32_e32 %[r2], %[d2], %[d2]\n\t")                                                                             \
+  "v_rsq_f32_e32 %[y], %[r2]\n\t"                                                                                         \
+  CNT_B                                                                                                                   \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_mul_f32_e32 %[y], %[r2], %[y]\n\t"                                                                                   \
+  "v_fma_f32 %[y], %[r2], %[y], %[eps]\n\t"                                                                               \
+  "v_rcp_f32_e32 %[y], %[y]\n\t"                                                                                          \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_mul_f32_e32 %[y], %[ms], %[y]\n\t"                                                                                   \
+  "v_fma_f32 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
+  "v_fma_f32 %[acc1], -%[y], %[d1], %[acc1]\n" Z("\t" "v_fma_f32 %[acc2], -%[y], %[d2], %[acc2]\n")                       \
+  ".LK9next%=:\n\t"                                                                                                       \
+  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                          \
+  "s_branch .LK9end%=\n"                                                                                                  \
+  ".LK9skip%=:\n\t"                                                                                                       \
+  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
+  "v_cmp_gt_u32_e64 %[wt], %[ka], %[key]\n\t"                                                                             \
+  "s_lshr_b32 %[t1], %[off], 1\n\t"                                                                                       \
+  "s_add_i32 %[t2], %[off], 32\n\t"                                                                                       \
+  "s_lshl1_add_u32 %[t3], %[spm1], 1\n\t"                                                                                 \
+  "s_bitcmp1_b32 %[off], 5\n\t"                                                                                           \
+  "s_cselect_b32 %[off], %[t2], %[t1]\n\t"                                                                                \
+  "s_cselect_b32 %[spm1], %[spm1], %[t3]\n\t"                                                                             \
+  "s_mov_b32 %[cur], %[ka]\n\t"                                                                                           \
+  "s_cmp_lg_u64 %[wt], 0\n\t"                                                                                             \
+  "s_cbranch_scc1 .LK9jump%=\n"                                                                                           \
+  ".LK9chk%=:\n\t"                                                                                                        \
+  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
+  "s_cbranch_scc1 .LK9load%=\n\t"                                                                                         \
+  "s_branch .LK9eval%=\n"                                                                                                 \
+  ".LK9jump%=:\n\t"                                                                                                       \
+  "s_mov_b64 vcc, %[wt]\n"                                                                                                \
+  ".LK9j1%=:\n\t"                                                                                                         \
+  "s_ff1_i32_b64 %[t1], vcc\n\t"                                                                                          \
+  "v_readlane_b32 %[cur], %[key], %[t1]\n\t"                                                                              \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_cmp_gt_u32_e32 vcc, %[cur], %[key]\n\t"                                                                              \
+  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                          \
+  "s_and_b32 %[t1], %[cur], 31\n\t"                                                                                       \
+  "s_sub_i32 %[t1], %[nlev], %[t1]\n\t"                                                                                   \
+  "s_lshl_b32 %[t2], -1, %[cur]\n\t"                                                                                      \
+  "s_not_b32 %[t2], %[t2]\n\t"                                                                                            \
+  "s_lshr_b32 %[t3], %[cur], 5\n\t"                                                                                       \
+  "s_lshr_b32 %[t3], %[t3], %[t1]\n\t"                                                                                    \
+  "s_add_i32 %[t3], %[t3], %[t2]\n\t"                                                                                     \
+  "s_lshl_b32 %[off], %[t3], 5\n\t"                                                                                       \
+  "s_lshl_b32 %[spm1], 32, %[t1]\n\t"                                                                                     \
+  "s_add_i32 %[spm1], %[spm1], -1\n\t"                                                                                    \
+  "s_branch .LK9chk%=\n"                                                                                                  \
+  ".LK9end%=:\n\t"                                                                                                        \
+  "s_mov_b64 exec, %[sv]"
 #define K9_KEEP(...) __VA_ARGS__
 #define K9_DROP(...) ""
 
-template <int D, bool COUNT>
-__global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<double>* __restrict__ node, double* __restrict__ a,
-                                                                 const double* __restrict__ x, double c, uint32_t sz, uint32_t first,
-                                                                 uint32_t count, double theta2, uint32_t nlevels,
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
+                                                                 const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
+                                                                 uint32_t count, T theta2, uint32_t nlevels,
                                                                  uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
                                                                  const uint32_t* __restrict__ nitems, uint32_t stride) {
-  static_assert(sizeof(tree_rec<double>) == 64, "the step program addresses 64-byte records");
+  static_assert(sizeof(tree_rec<T>) == 8 * sizeof(T), "the step program addresses records of 8 scalars");
   // work item of this block, as in bvh_force_wave_kernel
   uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
   if (items) {
@@ -1016,44 +1107,70 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   const bool valid     = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
   const uint32_t bi    = first + (valid ? local : 0u);
   uint32_t key         = valid ? 0u : 0xffffffffu;
-  double xs[3] = {0.0, 0.0, 0.0}, acc[3] = {0.0, 0.0, 0.0};
+  T xs[3] = {T(0), T(0), T(0)}, acc[3] = {T(0), T(0), T(0)};
 #pragma unroll
   for (int k = 0; k < D; ++k) xs[k] = x[uint64_t(bi) * D + k];
   uint32_t cn = 0, cl = 0, cm = 0, cb = 0;
   uint32_t cur = 0, off = 0, spm1 = (32u << nlevels) - 1u;
   const uint32_t endk = (sz << 5) - 1u;  // see bvh_force_wave_kernel
-  const pair_consts<double> pc;
-  double k0375 = 0.375, tiny = pair_math<double>::tiny, eps = DBL_EPSILON;
-  uint64_t nearhi = uint64_t(pair_math<double>::near_hi) << 32;
-  int m52 = -52;
-  // An accepted entry satisfies width^2 < fl(theta^2 d2); with d2 < 2^-16 that is <= theta^2 * 2^-16 (exact scaling), so only
-  // records whose width^2 has a high word <= that bound's — and body records, width^2 = -1, negative as an integer — can hold
-  // a near pair: a scalar compare decides whether the wave looks at all.
-  int khi, khi_v = int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1;
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(khi) : "v"(khi_v));  // (the product is computed by the vector unit)
-  asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
-  double d0, d1, d2, r2, t, y, y2, e, p, q;
-  uint32_t ka, t1, t2, t3, w2s, cinc;
-  uint64_t match, take, near, wt, sv;
-  double ms;
+  uint32_t ka, t1, t2, t3, cinc;
+  uint64_t match, take, wt, sv;
+#define K9_CLOBBER8 "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+  if constexpr (sizeof(T) == 8) {
+    const pair_consts<double> pc;
+    double k0375 = 0.375, tiny = pair_math<double>::tiny, eps = DBL_EPSILON;
+    uint64_t nearhi = uint64_t(pair_math<double>::near_hi) << 32;
+    int m52 = -52;
+    // An accepted entry satisfies width^2 < fl(theta^2 d2); with d2 < 2^-16 that is <= theta^2 * 2^-16 (exact scaling), so only
+    // records whose width^2 has a high word <= that bound's — and body records, width^2 = -1, negative as an integer — can hold
+    // a near pair: a scalar compare decides whether the wave looks at all.
+    int khi, khi_v = int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1;
+    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(khi) : "v"(khi_v));  // (the product is computed by the vector unit)
+    asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
+    double d0, d1, d2, r2, t, y, y2, e, p, q, ms;
+    uint32_t w2s;
+    uint64_t near;
 #define K9_OPERANDS                                                                                                        \
   : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
     [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
     [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q),    \
     [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take),              \
-    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms), [w2s] "=&s"(w2s), [cinc] "=&s"(cinc)                                                                     \
+    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms), [w2s] "=&s"(w2s), [cinc] "=&s"(cinc)               \
   : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi), \
-    [k0375] "s"(k0375), [m52] "s"(m52), [khi] "s"(khi), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
-    [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
-  : "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
-  if constexpr (D == 3) {
-    if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-    else asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", "", "") K9_OPERANDS);
-  } else {
-    if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-    else asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", "", "") K9_OPERANDS);
-  }
+    [k0375] "s"(k0375), [m52] "s"(m52), [khi] "s"(khi), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]),              \
+    [k15] "v"(pc.k15), [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                      \
+  : K9_CLOBBER8, "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
+    if constexpr (D == 3) {
+      if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", "", "") K9_OPERANDS);
+    } else {
+      if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", "", "") K9_OPERANDS);
+    }
 #undef K9_OPERANDS
+  } else {
+    float tiny = pair_math<float>::tiny, eps = FLT_EPSILON;
+    asm volatile("" : "+s"(tiny), "+s"(eps));
+    float d0, d1, d2, r2, t, y, ms;
+#define K9_OPERANDS                                                                                                        \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
+    [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
+    [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2),            \
+    [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms),              \
+    [cinc] "=&s"(cinc)                                                                                                     \
+  : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]),        \
+    [xs2] "v"(xs[2]), [tiny] "s"(tiny), [eps] "s"(eps), [bi] "v"(bi)                                                       \
+  : K9_CLOBBER8
+    if constexpr (D == 3) {
+      if constexpr (COUNT) asm volatile(K9_ISA_TEXT_F32(K9_KEEP, "s67", "s69", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_ISA_TEXT_F32(K9_KEEP, "s67", "s69", "", "") K9_OPERANDS);
+    } else {
+      if constexpr (COUNT) asm volatile(K9_ISA_TEXT_F32(K9_DROP, "s66", "s68", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_ISA_TEXT_F32(K9_DROP, "s66", "s68", "", "") K9_OPERANDS);
+    }
+#undef K9_OPERANDS
+  }
+#undef K9_CLOBBER8
   if (valid) {
 #pragma unroll
     for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
@@ -1148,10 +1265,10 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
   // 256 CUs (ms per whole bvh step over the first 200 steps of the galaxy, sweep / per-lane): f64 (hand-scheduled sweep) 0.90 / 0.85
   // at 4*10^4, 1.0 / 1.0 at 6*10^4, 1.1 / 1.15 at 8*10^4, 1.2 / 1.25 at 10^5, 1.3 / 1.5 at 1.3*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1
-  // at 5*10^5; f32 (compiler-scheduled) 1.75 / 1.45 at 2*10^5, 2.2 / 2.5 at 3*10^5, 2.7 / 3.4 at 4*10^5.  A system that has
+  // at 5*10^5; f32 0.90 / 0.65 at 6*10^4, 1.05 / 0.80 at 10^5, 1.25 / 1.15 at 1.6*10^5, 1.5 / 1.9 at 2.5*10^5, 4.45 / 10.6 at 10^6.  A system that has
   // evolved favours the sweep further: escapers inflate the box, walks get 3x longer and the per-lane form's divergent
   // gathers pay for every entry (10^5 bodies after 400-1000 steps: sweep 1.7-2.1 ms, per-lane 3.0-3.7 ms per traversal).
-  const uint32_t crossover = sizeof(T) == 8 ? 50000u : 250000u;
+  const uint32_t crossover = sizeof(T) == 8 ? 50000u : 180000u;
   int traversal = t->traversal;
   if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
@@ -1163,13 +1280,9 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
   // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
   const int bpl            = traversal == 4 ? 2 : 1;
-  // f64: the step program written out as ISA (bvh_force_sweep_isa_kernel) is the sweep that auto and 2 select; 5 forces it, 3 keeps
-  // the compiler-scheduled form (f32 always).  All forms are bitwise identical.
-  const bool isa = sizeof(T) == 8 && wave && (traversal == 0 || traversal == 2 || traversal == 5);
-  if (traversal == 5 && sizeof(T) != 8) {
-    set_error("traversal 5 (hand-scheduled sweep) exists for double precision only");
-    return NBODY_ERR_ARG;
-  }
+  // The step program written out as ISA (bvh_force_sweep_isa_kernel) is the sweep that auto and 2 select; 5 forces it, 3 keeps
+  // the compiler-scheduled form.  All forms are bitwise identical.
+  const bool isa = wave && (traversal == 0 || traversal == 2 || traversal == 5);
   const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
   const uint32_t blocks    = (s->count + per_block - 1) / per_block;
 #define NB_ARGS                                                                                                   \
@@ -1201,10 +1314,8 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
   } else if (wave && isa) {
-    if constexpr (sizeof(T) == 8) {
-      if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<D, true>), NB_WARGS);
-      else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<D, false>), NB_WARGS);
-    }
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, true>), NB_WARGS);
+    else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_WARGS);
   } else if (wave) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
@@ -1308,7 +1419,7 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
 
 extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
-  NB_ARG(mode >= 0 && mode <= 5, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep, double only), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 5, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep), got %d", mode);
   t->traversal = mode;
   return NBODY_OK;
 }

@@ -95,7 +95,7 @@ def test_bvh_randomized_systems_bit_exact(nb, oracle):
         dtype, dim = int(rng.integers(0, 2)), int(rng.integers(2, 4))
         n = int(rng.integers(2, 3000))
         theta = float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.4]))
-        modes = (1, 3, 4, 5, 2) if dtype == 1 else (1, 3, 4)  # 5 / 2: the hand-scheduled sweep (double only)
+        modes = (1, 3, 4, 5, 2)  # 5 / 2: the hand-scheduled sweep
         _phases(nb, oracle, dtype, dim, None, n, theta, counts=True, traversal=modes[case % len(modes)],
                 system=_random_system(nb, oracle, rng, dtype, dim, n))
 
@@ -107,8 +107,8 @@ def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
     for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0),
                               (3, "uniform", 4096, 3.0), (2, "galaxy", 64, 2.5)):
         res = []
-        # per-lane walks; compiler-scheduled sweep with 1 and with 2 bodies per lane; the sweep written as ISA (double only)
-        for mode in (1, 3, 4) + ((5,) if dtype == 1 else ()):
+        # per-lane walks; compiler-scheduled sweep with 1 and with 2 bodies per lane; the sweep written as ISA
+        for mode in (1, 3, 4, 5):
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.bvh.set_traversal(mode)
             dev.bvh.enable_counters(True)
@@ -267,7 +267,7 @@ def test_traversal_terminates_on_nan_and_inf_positions():
         nb = load_package()
         for bad in (np.nan, np.inf, -np.inf):
             for dtype in (1, 0):
-                for mode in (1, 3) + ((5,) if dtype == 1 else ()):
+                for mode in (1, 3, 5):
                     hs = nb.build_model(dtype, 3, "galaxy", 5000)
                     hs.x[17, 0] = bad; hs.x[4000, 2] = bad; hs.x[4999] = bad
                     dev = nb.DeviceSystem.from_host(hs)

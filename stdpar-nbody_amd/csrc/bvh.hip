@@ -829,7 +829,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9, the sweep's step program written out as ISA (f64).
+// K9, the sweep's step program written out as ISA (f64 described; the f32 text follows it).
 //
 // The sweep above is bound by the number of instructions a step issues (vector and scalar halves barely overlap: a wave's
 // step is one dependent chain).  hipcc's schedule of the C++ step is 61 instructions; this is the same step — same tests,
@@ -841,9 +841,14 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
 //     test for "somebody descends" (its SCC);
 //   * the position is (cur, off, span - 1): the skip key is ONE s_addc_u32 (cur + (span - 1) + "is a left child", the latter
 //     read by s_bitcmp1 from the byte offset), the child's offset one s_lshl1_add_u32;
-//   * descend and skip are two short tails instead of eight computed candidates and four selects.
-// 36-39 instructions per step instead of 61.  The opening test is !(width^2 >= theta^2 d^2): for numbers the reference's
-// `<`, for a NaN distance "accept" — a walk cannot descend below the body level whatever the state holds.
+//   * descend and skip are two short tails instead of eight computed candidates and four selects;
+//   * a scalar compare on the record's width^2 decides whether the wave looks for near pairs at all;
+//   * the NEXT record is requested as soon as the decision is made, before the accepted term of the current one is evaluated
+//     (its mass and width^2 are copied to spare SGPRs first; VALU instructions read their scalar operands at issue, so the
+//     record registers may be overwritten by a load issued after them).
+// Measured: 23.4 VALU + 18.1 SALU + 5.5 branch + 1 SMEM instructions per step instead of 29 + 26 + 4.3 + 1; config 4 8.9 -> 7.0 ms.
+// The opening test is !(width^2 >= theta^2 d^2): for numbers the reference's `<`, for a NaN distance "accept" — a walk
+// cannot descend below the body level whatever the state holds.
 // Hazards are handled by hand inside the block (gfx940 rules: a transcendental's result needs one instruction before its
 // first use, an SGPR written by a VALU instruction two before a VALU instruction reads it; SALU readers interlock).
 // The record lives in s[64:79] (fields are addressed as sub-ranges, which an asm operand cannot express).

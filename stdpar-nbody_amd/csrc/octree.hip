@@ -865,6 +865,275 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   }
 }
 
+// the accepted term's weight for d2 >= 2^-46 (ot_accumulate's far form, same operations in the same order); v[60:61] = mass
+#define OT_FAR                                                                                                            \
+  "v_mul_f64 %[y2], %[y], %[y]\n\t"                                                                                       \
+  "v_fma_f64 %[e], -%[r2], %[y2], 1.0\n\t"                                                                                \
+  "v_mul_f64 %[y2], %[y], %[y2]\n\t"                                                                                      \
+  "v_fma_f64 %[p], %[k1875], %[e], %[k15]\n\t"                                                                            \
+  "v_mul_f64 %[g], %[y], %[m3eps]\n\t"                                                                                    \
+  "v_fmac_f64_e32 %[g], %[p], %[e]\n\t"                                                                                   \
+  "v_mul_f64 %[w], v[60:61], %[y2]\n\t"                                                                                   \
+  "v_fmac_f64_e32 %[w], %[w], %[g]\n\t"
+
+// One visit round of ot_force_kernel written out as ISA (double, 3D): see ot_force_isa_kernel.
+#define OT_ISA_TEXT(CNT_N, CNT_T)                                                                                         \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  "v_cmp_ne_u32_e32 vcc, 0, %[more]\n\t"                                                                                  \
+  "s_and_b64 exec, exec, vcc\n\t"                                                                                         \
+  "s_cbranch_execz .LOTend%=\n"                                                                                           \
+  ".LOTtop%=:\n\t"                                                                                                        \
+  "v_mad_u32_u24 %[oa], %[cur], %[s320], %[cc16]\n\t"                                                                     \
+  "v_mad_u32_u24 %[of], %[cur], %[s320], %[cc8]\n\t"                                                                      \
+  "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
+  "global_load_dwordx4 v[58:61], %[oa], %[groups] offset:128\n\t"                                                         \
+  "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"                                                                    \
+  CNT_N                                                                                                                   \
+  "s_waitcnt vmcnt(2)\n\t"                                                                                                \
+  "v_add_f64 %[d0], v[54:55], -%[xi0]\n\t"                                                                                \
+  "v_add_f64 %[d1], v[56:57], -%[xi1]\n\t"                                                                                \
+  "v_fma_f64 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
+  "s_waitcnt vmcnt(1)\n\t"                                                                                                \
+  "v_add_f64 %[d2], v[58:59], -%[xi2]\n\t"                                                                                \
+  "v_fmac_f64_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
+  "v_fmac_f64_e32 %[r2], %[d2], %[d2]\n\t"                                                                                \
+  "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
+  "s_waitcnt vmcnt(0)\n\t"                                                                                                \
+  "v_sub_u32_e32 %[t], 0, v63\n\t"                                                                                        \
+  "v_ldexp_f64 %[g], %[rootside], %[t]\n\t"                                                                               \
+  "v_cmp_gt_u32_e64 %[nonleaf], -2, v62\n\t"                                                                              \
+  "v_mul_f64 %[w], %[g], %[y]\n\t"                                                                                        \
+  "v_cmp_lt_f64_e64 %[st], %[w], %[lo]\n\t"                                                                               \
+  "v_cmp_gt_f64_e64 %[so], %[w], %[hi]\n\t"                                                                               \
+  "v_cmp_lt_f64_e64 %[so2], %[y], %[c35]\n\t"                                                                             \
+  "s_and_b64 %[so], %[so], %[so2]\n\t"                                                                                    \
+  "s_or_b64 %[so], %[so], %[st]\n\t"                                                                                      \
+  "s_andn2_b64 %[so], %[nonleaf], %[so]\n\t"                                                                              \
+  "s_cbranch_scc1 .LOTexact%=\n"                                                                                          \
+  ".LOTdecided%=:\n\t"                                                                                                    \
+  "s_andn2_b64 %[take], exec, %[nonleaf]\n\t"                                                                             \
+  "s_or_b64 %[take], %[take], %[st]\n\t"                                                                                  \
+  "s_mov_b64 %[act], exec\n\t"                                                                                            \
+  "s_andn2_b64 %[open], exec, %[take]\n\t"                                                                                \
+  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
+  "s_cbranch_scc0 .LOTnotake%=\n\t"                                                                                       \
+  OT_FAR                                                                                                                  \
+  "v_cmp_gt_u64_e64 %[near], %[nearhi], %[r2]\n\t"                                                                        \
+  CNT_T                                                                                                                   \
+  "s_cmp_lg_u64 %[near], 0\n\t"                                                                                           \
+  "s_cbranch_scc1 .LOTnear%=\n"                                                                                           \
+  ".LOTacc%=:\n\t"                                                                                                        \
+  "v_fmac_f64_e32 %[acc0], %[w], %[d0]\n\t"                                                                               \
+  "v_fmac_f64_e32 %[acc1], %[w], %[d1]\n\t"                                                                               \
+  "v_fmac_f64_e32 %[acc2], %[w], %[d2]\n"                                                                                 \
+  ".LOTnotake%=:\n\t"                                                                                                     \
+  /* the children to open go on the body's stack in reverse child order; the 2^D lanes of a body pop the same entry */    \
+  "s_mov_b64 exec, %[act]\n\t"                                                                                            \
+  "v_lshrrev_b64 v[52:53], %[gshift], %[open]\n\t"                                                                        \
+  "v_and_b32_e32 v52, 0xff, v52\n\t"                                                                                      \
+  "v_bcnt_u32_b32 %[nsp], v52, %[sp]\n\t"                                                                                 \
+  "s_and_b64 exec, %[open], %[open]\n\t"                                                                                  \
+  "v_lshrrev_b32_e32 v53, %[ccp1], v52\n\t"                                                                               \
+  "v_bcnt_u32_b32 v53, v53, %[sp]\n\t"                                                                                    \
+  "v_lshl_add_u32 v53, v53, 5, %[stk]\n\t"                                                                                \
+  "ds_write_b32 v53, v62\n\t"                                                                                             \
+  "s_mov_b64 exec, %[act]\n\t"                                                                                            \
+  "v_add_u32_e32 %[sp], -1, %[nsp]\n\t"                                                                                   \
+  "v_cmpx_gt_u32_e64 %[act], %[depth], %[sp]\n\t"                                                                         \
+  "s_cbranch_execz .LOTend%=\n\t"                                                                                         \
+  "v_lshl_add_u32 v53, %[sp], 5, %[stk]\n\t"                                                                              \
+  "ds_read_b32 %[cur], v53\n\t"                                                                                           \
+  "s_add_i32 %[guard], %[guard], -1\n\t"                                                                                  \
+  "s_cmp_lg_u32 %[guard], 0\n\t"                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
+  "s_cbranch_scc1 .LOTtop%=\n\t"                                                                                          \
+  "s_mov_b32 %[gflag], 1\n\t"                                                                                             \
+  "s_branch .LOTend%=\n"                                                                                                  \
+  ".LOTexact%=:\n\t" /* some lane is inside the guard band: the reference's expression with IEEE sqrt and divide, for every lane (ot_accept) */\
+  "v_mul_f64 v[52:53], %[d0], %[d0]\n\t"                                                                                  \
+  "v_mul_f64 v[54:55], %[d1], %[d1]\n\t"                                                                                  \
+  "v_add_f64 v[52:53], v[52:53], v[54:55]\n\t"                                                                            \
+  "v_mul_f64 v[54:55], %[d2], %[d2]\n\t"                                                                                  \
+  "v_add_f64 v[52:53], v[54:55], v[52:53]\n\t"                                                                            \
+  "v_cmp_gt_f64_e32 vcc, %[sqmin], v[52:53]\n\t"                                                                          \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_mov_b32_e32 %[oa], 0x100\n\t"                                                                                          \
+  "v_cndmask_b32_e32 %[t], 0, %[oa], vcc\n\t"                                                                           \
+  "v_ldexp_f64 v[52:53], v[52:53], %[t]\n\t"                                                                              \
+  "v_rsq_f64_e32 v[54:55], v[52:53]\n\t"                                                                                  \
+  "v_mov_b32_e32 %[oa], 0xffffff80\n\t"                                                                                     \
+  "v_cndmask_b32_e32 %[t], 0, %[oa], vcc\n\t"                                                                           \
+  "v_cmp_class_f64_e64 vcc, v[52:53], %[c260]\n\t"                                                                        \
+  "v_mul_f64 v[56:57], v[52:53], v[54:55]\n\t"                                                                            \
+  "v_mul_f64 v[54:55], v[54:55], 0.5\n\t"                                                                                 \
+  "v_fma_f64 v[58:59], -v[54:55], v[56:57], 0.5\n\t"                                                                      \
+  "v_fmac_f64_e32 v[56:57], v[56:57], v[58:59]\n\t"                                                                       \
+  "v_fma_f64 %[w], -v[56:57], v[56:57], v[52:53]\n\t"                                                                     \
+  "v_fmac_f64_e32 v[54:55], v[54:55], v[58:59]\n\t"                                                                       \
+  "v_fmac_f64_e32 v[56:57], %[w], v[54:55]\n\t"                                                                           \
+  "v_fma_f64 v[58:59], -v[56:57], v[56:57], v[52:53]\n\t"                                                                 \
+  "v_fmac_f64_e32 v[56:57], v[58:59], v[54:55]\n\t"                                                                       \
+  "v_ldexp_f64 v[54:55], v[56:57], %[t]\n\t"                                                                              \
+  "v_cndmask_b32_e32 v53, v55, v53, vcc\n\t"                                                                              \
+  "v_cndmask_b32_e32 v52, v54, v52, vcc\n\t"                                                                              \
+  "v_add_f64 v[52:53], v[52:53], %[eps]\n\t"                                                                              \
+  "v_div_scale_f64 v[54:55], %[so2], v[52:53], v[52:53], %[g]\n\t"                                                        \
+  "v_rcp_f64_e32 v[56:57], v[54:55]\n\t"                                                                                  \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_fma_f64 v[58:59], -v[54:55], v[56:57], 1.0\n\t"                                                                      \
+  "v_fmac_f64_e32 v[56:57], v[56:57], v[58:59]\n\t"                                                                       \
+  "v_fma_f64 v[58:59], -v[54:55], v[56:57], 1.0\n\t"                                                                      \
+  "v_fmac_f64_e32 v[56:57], v[56:57], v[58:59]\n\t"                                                                       \
+  "v_div_scale_f64 v[58:59], vcc, %[g], v[52:53], %[g]\n\t"                                                               \
+  "v_mul_f64 %[w], v[58:59], v[56:57]\n\t"                                                                                \
+  "v_fma_f64 v[54:55], -v[54:55], %[w], v[58:59]\n\t"                                                                     \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_div_fmas_f64 v[54:55], v[54:55], v[56:57], %[w]\n\t"                                                                 \
+  "v_div_fixup_f64 v[52:53], v[54:55], v[52:53], %[g]\n\t"                                                                \
+  "v_cmp_gt_f64_e64 %[st], %[theta], v[52:53]\n\t"                                                                        \
+  "s_branch .LOTdecided%=\n"                                                                                              \
+  ".LOTnear%=:\n\t" /* an accepted child closer than 2^-23 (the body's own leaf, coincident bodies): the guarded form, per lane */\
+  "s_mov_b64 %[so], exec\n\t"                                                                                             \
+  "s_mov_b64 exec, %[near]\n\t"                                                                                           \
+  "v_mul_f64 %[y2], %[r2], %[y]\n\t"                                                                                      \
+  "v_fma_f64 %[e], -%[y2], %[y], 1.0\n\t"                                                                                 \
+  "v_mul_f64 %[p], %[y2], 0.5\n\t"                                                                                        \
+  "v_fmac_f64_e32 %[y2], %[p], %[e]\n\t"                                                                                  \
+  "v_add_f64 %[y2], %[y2], %[eps]\n\t"                                                                                    \
+  "v_mul_f64 %[e], %[y2], %[y2]\n\t"                                                                                      \
+  "v_mul_f64 %[y2], %[y2], %[e]\n\t"                                                                                      \
+  "v_rcp_f64_e32 %[e], %[y2]\n\t"                                                                                         \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_fma_f64 %[y2], -%[y2], %[e], 1.0\n\t"                                                                                \
+  "v_fmac_f64_e32 %[e], %[e], %[y2]\n\t"                                                                                  \
+  "v_mul_f64 %[w], v[60:61], %[e]\n\t"                                                                                    \
+  "s_mov_b64 exec, %[so]\n\t"                                                                                             \
+  "s_branch .LOTacc%=\n"                                                                                                  \
+  ".LOTend%=:\n\t"                                                                                                        \
+  "s_mov_b64 exec, %[sv]"
+
+// A wave-uniform double that the vector unit computed, moved to an SGPR pair (opaque to the optimizer, which would fold a
+// readfirstlane of a value it knows to be uniform and then fail to satisfy an "s" constraint).
+__device__ __forceinline__ double ot_to_sgpr(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  uint32_t lo, hi;
+  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(uint32_t(b)), "v"(uint32_t(b >> 32)));
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
+
+// The walk of ot_force_kernel for double precision in 3D with its visit round written as ISA — the same tests, the same
+// arithmetic in the same order, bitwise the same results, counters and flags.  hipcc's schedule of the C++ round is ~96
+// instructions (50 VALU): predicated weights, mask round trips through v_cndmask/v_cmp, one saveexec/branch pair per `if`.
+// Here a round is ~60 (36 VALU): record addresses are 32-bit offsets from an SGPR base (two v_mad_u32_u24 instead of 64-bit
+// multiply-adds), the conditions live in scalar masks and EXEC (accepted term under EXEC = take, push under EXEC = open), the
+// step budget is one scalar counter for the wave (its lanes make the same rounds), and "stack empty" and "stack full" are ONE
+// unsigned compare on sp - 1 (the stacks are entry-major in LDS, so a round that overflows writes past the END of the block's
+// LDS, where the hardware drops it; the lane then leaves and reports kFlagStack).  The records of the round live in v[52:63] (their halves are addressed
+// separately, which an asm operand cannot express).  Group offsets are 32 bits: the host uses this kernel while the group
+// array is below 4 GiB (N <= 1.3e7).
+template <bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>* __restrict__ rootrec,
+                                                          const ot_group<double, 3>* __restrict__ groups,
+                                                          const uint32_t* __restrict__ list, uint32_t nlist,
+                                                          const double* __restrict__ x, double* __restrict__ a, double c,
+                                                          uint32_t first, double theta, uint32_t capacity,
+                                                          const double* __restrict__ root, uint32_t* __restrict__ flags,
+                                                          uint32_t* __restrict__ counters) {
+  using T = double;
+  constexpr int D = 3;
+  constexpr uint32_t NCH = 8, GPW = 8;
+  constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;
+  static_assert(sizeof(ot_group<double, 3>) == 320, "the round addresses 320-byte sibling groups");
+  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * 8 + g) * 4
+  const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
+  const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
+  const bool valid    = t < nlist;
+  const uint32_t body = valid ? list[t] : first;
+  const ot_theta<T> th(theta);
+  const pair_consts<T> pc;
+  const T root_side = root[D];
+  T xi[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
+    acc[k] = T(0);
+  }
+  uint32_t c_nodes = 0, c_terms = 0;
+  uint32_t cur = 0;
+  bool more = false;
+  if (valid) {  // the root is examined alone, exactly as in ot_force_kernel
+    const ot_node<T> nd = *rootrec;
+    T di[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
+    const T d2f     = ot_dist2_fused<T, D>(di);
+    const T y0      = ot_rsq(d2f);
+    const bool leaf = nd.fc >= kOtBody;
+    const bool take = leaf || ot_accept<T, D>(!leaf, root_side, di, y0, th);
+    {
+      const bool on0    = take && cc == 0;
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(on0);
+      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, acc, di, nd.m, d2f, y0, pc);
+    }
+    if (COUNT && cc == 0) {
+      c_nodes = 1;
+      c_terms = take;
+    }
+    more = !take;
+    cur  = nd.fc;
+  }
+  // the rounds
+  uint32_t more_v = more ? 1u : 0u, sp = 0, nsp = 0, gflag = 0, guard = capacity;
+  const uint32_t cc16 = cc * 16u, cc8 = 256u + cc * 8u, gshift = threadIdx.x & 56u, ccp1 = cc + 1u;
+  const uint32_t stk = uint32_t(reinterpret_cast<uintptr_t>(&stack[0][g]));  // LDS byte address (low word of the flat one)
+  double lo = ot_to_sgpr(th.lo), hi = ot_to_sgpr(th.hi), thx = ot_to_sgpr(th.exact), c35 = 0x1p35, tiny = ot_consts<T>::tiny,
+         eps = ot_consts<T>::eps, m3eps = -(3.0 * ot_consts<T>::eps), sqmin = 0x1p-767, rs = ot_to_sgpr(root_side);
+  uint64_t nearhi = uint64_t(ot_near<T>::bits) << 32;
+  uint32_t s320 = 320u, depth = DEPTH, c260 = 0x260u;
+  asm volatile("" : "+s"(c35), "+s"(tiny), "+s"(eps), "+s"(m3eps), "+s"(sqmin), "+s"(nearhi), "+s"(s320), "+s"(depth), "+s"(c260));
+  double d0, d1, d2, r2, y, y2, e, p, gq, w;
+  uint32_t oa, of, tt;
+  uint64_t nonleaf, st, so, so2, take, open, act, sv, near;
+#define OT_OPERANDS                                                                                                        \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [cur] "+v"(cur), [sp] "+v"(sp), [nsp] "+v"(nsp),          \
+    OT_CNT_OPERANDS [guard] "+s"(guard), [gflag] "+s"(gflag), [d0] "=&v"(d0), [d1] "=&v"(d1),       \
+    [d2] "=&v"(d2), [r2] "=&v"(r2), [y] "=&v"(y), [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [g] "=&v"(gq), [w] "=&v"(w),  \
+    [oa] "=&v"(oa), [of] "=&v"(of), [t] "=&v"(tt), [nonleaf] "=&s"(nonleaf), [st] "=&s"(st), [so] "=&s"(so),               \
+    [so2] "=&s"(so2), [take] "=&s"(take), [open] "=&s"(open), [act] "=&s"(act), [sv] "=&s"(sv), [near] "=&s"(near)          \
+  : [more] "v"(more_v), [groups] "s"(groups), [xi0] "v"(xi[0]), [xi1] "v"(xi[1]), [xi2] "v"(xi[2]), [cc16] "v"(cc16),     \
+    [cc8] "v"(cc8), [gshift] "v"(gshift), [ccp1] "v"(ccp1), [stk] "v"(stk), [k15] "v"(pc.k15), [k1875] "s"(pc.k1875),       \
+    [lo] "s"(lo), [hi] "s"(hi), [theta] "s"(thx), [c35] "s"(c35), [tiny] "s"(tiny), [eps] "s"(eps), [m3eps] "s"(m3eps),    \
+    [sqmin] "s"(sqmin), [nearhi] "s"(nearhi), [rootside] "s"(rs), [s320] "s"(s320), [depth] "s"(depth), [c260] "s"(c260)                                                                                     \
+  : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define OT_CNT_OPERANDS [cn] "+v"(c_nodes), [ct] "+v"(c_terms),
+  if constexpr (COUNT) asm volatile(OT_ISA_TEXT("v_add_u32_e32 %[cn], 1, %[cn]\n\t", "v_add_u32_e32 %[ct], 1, %[ct]\n\t") OT_OPERANDS);
+#undef OT_CNT_OPERANDS
+#define OT_CNT_OPERANDS
+  if constexpr (!COUNT) asm volatile(OT_ISA_TEXT("", "") OT_OPERANDS);
+#undef OT_CNT_OPERANDS
+#undef OT_OPERANDS
+  if (more && nsp > DEPTH && cc == 0) atomicOr(flags, kFlagStack);  // a stack ran full: reported by nbody_octree_info
+  if (gflag != 0u && threadIdx.x == 0) atomicOr(flags, kFlagWalk);             // step budget spent: the tree is damaged
+  // combine the 2^D partial sums of a body (fixed order)
+#pragma unroll
+  for (uint32_t off = NCH / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] += __shfl_xor(acc[k], int(off), 64);
+    if (COUNT) {
+      c_nodes += __shfl_xor(c_nodes, int(off), 64);
+      c_terms += __shfl_xor(c_terms, int(off), 64);
+    }
+  }
+  if (valid && cc == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(body) * 2 + 0] = c_nodes;
+      counters[uint64_t(body) * 2 + 1] = c_terms;
+    }
+  }
+}
+
 }  // namespace nbody
 
 // ---- host side / C ABI -----------------------------------------------------------------------------------------------
@@ -981,7 +1250,25 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
                      static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root),                                   \
                      t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
-  if (t->counters_on) NB_OT_LAUNCH(true);
+  // double, 3D: the visit round written as ISA (ot_force_isa_kernel), while 32-bit group offsets reach the whole array;
+  // NBODY_OT_FORM=1 keeps the compiler-scheduled kernel (tests compare the two bitwise)
+  bool isa = false;
+  if constexpr (sizeof(T) == 8 && D == 3) {
+    const char* fe = getenv("NBODY_OT_FORM");
+    isa            = !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32);
+  }
+  if (isa) {
+    if constexpr (sizeof(T) == 8 && D == 3) {
+#define NB_OT_ISA(CNT)                                                                                                       \
+  hipLaunchKernelGGL((ot_force_isa_kernel<CNT>), dim3(blocks), dim3(64), 0, st, rootrec,                                     \
+                     static_cast<const ot_group<T, D>*>(t->groups), list, s->count, static_cast<const T*>(s->x),            \
+                     static_cast<T*>(s->a), static_cast<T>(s->c), s->first, static_cast<T>(theta), t->capacity,             \
+                     static_cast<const T*>(t->root), t->lvl_count + (kMaxLevels<3> + 2), t->counters)
+      if (t->counters_on) NB_OT_ISA(true);
+      else NB_OT_ISA(false);
+#undef NB_OT_ISA
+    }
+  } else if (t->counters_on) NB_OT_LAUNCH(true);
   else NB_OT_LAUNCH(false);
 #undef NB_OT_LAUNCH
   NB_HIP(hipGetLastError());

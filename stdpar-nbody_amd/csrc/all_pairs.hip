@@ -361,15 +361,18 @@ struct k1_plan {
 
 static int auto_split(uint32_t sz) { return sz >= 2048u ? 8 : 4; }
 
-// Chunks from sz alone: min(16, tiles, 2^22 / sz rounded up to a power of two) — 4 at N = 2^20 (whole system: 32 768
-// blocks; a 1/8 shard: 4096), 16 from 262 144 down to 8192 bodies, one tile per chunk below that.  Measured
-// (profiles/r02/k1_chunks_tuning.txt, gpurun_out/r02/tune_small.txt; f64, ms per pass, chunks 1 / this rule):
-// N = 4096: 0.070 / 0.023, 10^4: 0.166 / 0.083, 3*10^4: 0.66 / 0.57, 65 536: 2.64 / 2.50, 10^5: 7.45 / 5.81,
-// 2^20: 637 / 635, its 1/8 shard: 83.8 / 80.6.  More chunks than this change nothing (N = 10^5: 64 chunks 5.87 ms).
+// Chunks from sz alone: 16, or more where 16 would leave a chunk above 65 536 records (up to 64), and never more than tiles.
+//   * at least 16: every size runs >= 16 rounds of short blocks and small systems get the waves the scalar stream needs.
+//     Measured (profiles/r02/k1_chunks_tuning.txt, k1_small_n_tuning.txt; f64, ms per pass, chunks 1 / 16): N = 4096: 0.070 /
+//     0.023, 10^4: 0.166 / 0.083, 3*10^4: 0.66 / 0.57, 65 536: 2.64 / 2.50, 10^5: 7.45 / 5.81; more change nothing (N = 10^5:
+//     64 chunks 5.87 ms).
+//   * chunks of at most 65 536 records (2 MB in f64): blocks are dispatched x-fastest, so the blocks in flight on an XCD stream
+//     the SAME chunk, and a chunk of half the XCD's 4 MiB L2 stays there.  N = 2^20 (rocprofv3 FETCH_SIZE per launch, kernel
+//     time unchanged within 0.2 %): 4 chunks of 8 MB 8.4 GB, 8 chunks 4.7 GB, 16 chunks of 2 MB 0.46 GB.
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk) {
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
-  uint32_t y = 1;
-  while (y < 16 && uint64_t(y) * sz < (1ull << 22)) y *= 2;
+  uint32_t y = 16;
+  while (y < 64 && uint64_t(y) * 65536u < sz) y *= 2;
   if (y > ntiles) y = ntiles ? ntiles : 1;
   uint32_t tpc = ntiles ? (ntiles + y - 1) / y : 1;
   *tiles_per_chunk = tpc;

@@ -253,3 +253,19 @@ def test_multi_gpu_abi_from_plain_c(tmp_path):
     assert r.returncode == 0, r.stderr
     r = subprocess.run([exe, "1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "bitwise equal" in r.stdout, r.stdout + r.stderr
+
+
+def test_scheduling_forms_give_the_same_trajectory():
+    """K9's per-lane walks, its compiler-scheduled sweep and the sweep written as ISA — and the octree walk's two forms — are
+    bitwise equal per force phase (tests/test_gpu_bvh.py, test_gpu_octree.py); here over a few hundred steps of an evolving
+    system in the CLI's recorded step loop (trees deepen as escapers inflate the box): --print-state text identical."""
+    strip = lambda out: re.sub(r"Total time: .*", "", out)
+    for prec, n, steps in (("double", 60000, 300), ("float", 70000, 150)):
+        args = ["-n", n, "-s", steps, "--precision", prec, "--algorithm", "bvh", "--workload", "galaxy", "--print-state"]
+        outs = [cli_env(3, args, {"NBODY_K9_MODE": m}) for m in ("1", "3", "5")]
+        assert all(o.returncode == 0 for o in outs), [o.stderr[-300:] for o in outs]
+        assert strip(outs[0].stdout) == strip(outs[1].stdout) == strip(outs[2].stdout), prec
+    args = ["-n", 50000, "-s", 400, "--precision", "double", "--algorithm", "octree", "--workload", "galaxy", "--print-state"]
+    a, b = cli_env(3, args, {"NBODY_OT_FORM": "0"}), cli_env(3, args, {"NBODY_OT_FORM": "1"})
+    assert a.returncode == 0 and b.returncode == 0, a.stderr[-300:] + b.stderr[-300:]
+    assert strip(a.stdout) == strip(b.stdout)

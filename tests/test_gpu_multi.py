@@ -110,7 +110,7 @@ def test_sharded_context_download_places_rows(nb):
     assert np.array_equal(out.x, ref.x) and np.array_equal(out.v, ref.v) and np.array_equal(out.a, ref.a)
 
 
-def _two_rank_worker(rank, world, port, n, steps, q):
+def _two_rank_worker(rank, world, port, n, steps, q, algo="all-pairs"):
     """One of two real rank processes sharing the box's one GPU: HIP kernels on its shard window, K3, exchange."""
     import torch
     import torch.distributed as dist
@@ -123,7 +123,10 @@ def _two_rank_worker(rank, world, port, n, steps, q):
     nb = load_package()
     torch.cuda.set_device(0)
     hs = nb.build_model(nb.F64, 3, "galaxy", n)
-    sim = nb.parallel.ShardedAllPairs(hs, rank, world, torch_device=torch.device("cuda", 0))
+    if algo == "octree":
+        sim = nb.parallel.ShardedOctree(hs, rank, world, theta=0.5, torch_device=torch.device("cuda", 0))
+    else:
+        sim = nb.parallel.ShardedAllPairs(hs, rank, world, torch_device=torch.device("cuda", 0))
     for _ in range(steps):
         sim.step()
     torch.cuda.synchronize()
@@ -134,12 +137,13 @@ def _two_rank_worker(rank, world, port, n, steps, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n,world", [(70001, 2), (8192, 3)])
-def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world):
+@pytest.mark.parametrize("n,world,algo", [(70001, 2, "all-pairs"), (8192, 3, "all-pairs"), (30001, 2, "octree")])
+def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world, algo):
     """ranks as real processes, each launching the HIP kernels on its own shard window and exchanging positions
     every step, against the single-GPU trajectory — bitwise in x, v, a.  Both ranks use the box's one MI355X, so the
     process group is gloo and the shards are staged through the host (the RCCL exchange itself needs one GPU per rank);
-    70001 bodies: uneven shards, the 8-slice scalar-stream K1 with source chunks."""
+    70001 bodies: uneven shards, the 8-slice scalar-stream K1 with source chunks; the octree case: every rank rebuilds the
+    whole tree from the gathered positions and walks it for its own bodies (ShardedOctree)."""
     import socket
     import torch.multiprocessing as mp
     steps = 3
@@ -148,7 +152,7 @@ def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world):
         port = sk.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, steps, q)) for r in range(world)]
+    procs = [ctx.Process(target=_two_rank_worker, args=(r, world, port, n, steps, q, algo)) for r in range(world)]
     for p in procs:
         p.start()
     x, v, a = q.get(timeout=600)
@@ -156,7 +160,7 @@ def test_two_rank_processes_on_one_gpu_equal_single_gpu(nb, n, world):
         p.join(timeout=120)
         assert p.exitcode == 0
     dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "galaxy", n))
-    nb.run(dev, "all-pairs", steps)
+    nb.run(dev, algo, steps, 0.5)
     ref = dev.download()
     assert np.array_equal(x, ref.x) and np.array_equal(v, ref.v) and np.array_equal(a, ref.a)
 

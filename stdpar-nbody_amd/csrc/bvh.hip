@@ -1273,7 +1273,9 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // at 5*10^5; f32 0.90 / 0.65 at 6*10^4, 1.05 / 0.80 at 10^5, 1.25 / 1.15 at 1.6*10^5, 1.5 / 1.9 at 2.5*10^5, 4.45 / 10.6 at 10^6.  A system that has
   // evolved favours the sweep further: escapers inflate the box, walks get 3x longer and the per-lane form's divergent
   // gathers pay for every entry (10^5 bodies after 400-1000 steps: sweep 1.7-2.1 ms, per-lane 3.0-3.7 ms per traversal).
-  const uint32_t crossover = sizeof(T) == 8 ? 50000u : 180000u;
+  // f64 below 5*10^4: the first steps of the galaxy favour the per-lane form by 7 % (4*10^4) to 20 % (10^4), its evolved states the
+  // sweep by 25-40 % (whole 1000-step runs, sweep / per-lane: 0.86 / 0.91 s at 10^4, 0.99 / 1.07 at 2*10^4, 1.16 / 1.47 at 3*10^4)
+  const uint32_t crossover = sizeof(T) == 8 ? 30000u : 180000u;
   int traversal = t->traversal;
   if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);

@@ -632,6 +632,7 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
 
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
+  const pair_consts<T> pc;
 
   // 64 targets per wave: lane l owns target i0 + l
   const uint32_t i0   = (blockIdx.x * kWaves + wave) * 64;
@@ -681,25 +682,43 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
 #pragma unroll
         for (int k = 0; k < D; ++k) xg[tt][k] = lane_bcast(xt[k], g * NT + tt);
       T part[D][NT];
+      // f64: first with the reciprocal-free weight and no near-pair handling at all; a (group, tile) block that held a pair
+      // closer than 2^-8 — the tile with the group's own bodies, a very close pair — is recomputed with the guarded form
+      bool guarded = sizeof(T) == 4;
+      for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int k = 0; k < D; ++k)
+        for (int k = 0; k < D; ++k)
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) part[k][tt] = T(0);
+          for (int tt = 0; tt < NT; ++tt) part[k][tt] = T(0);
+        uint32_t lowest = 0xffffffffu;
 #pragma unroll 1
-      for (int sub = 0; sub < SUBS; ++sub) {
-        rec_t src[KS];
+        for (int sub = 0; sub < SUBS; ++sub) {
+          rec_t src[KS];
 #pragma unroll
-        for (int q = 0; q < KS; ++q) src[q] = tile[(sub * KS + q) * 64 + lane];
+          for (int q = 0; q < KS; ++q) src[q] = tile[(sub * KS + q) * 64 + lane];
 #pragma unroll
-        for (int tt = 0; tt < NT; ++tt) {
-          T pt[D];
+          for (int tt = 0; tt < NT; ++tt) {
+            T pt[D];
 #pragma unroll
-          for (int k = 0; k < D; ++k) pt[k] = part[k][tt];
+            for (int k = 0; k < D; ++k) pt[k] = part[k][tt];
+            if constexpr (sizeof(T) == 8) {
+              if (guarded) {
 #pragma unroll
-          for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);
+                for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);
+              } else {
 #pragma unroll
-          for (int k = 0; k < D; ++k) part[k][tt] = pt[k];
+                for (int q = 0; q < KS; q += NB) pair_accumulate_far<D, NB>(pt, xg[tt], &src[q], lowest, pc.k15, pc.k1875);
+              }
+            } else {
+#pragma unroll
+              for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) part[k][tt] = pt[k];
+          }
         }
+        if (guarded || __builtin_amdgcn_ballot_w64(lowest < pair_math<double>::near_hi) == 0ull) break;
+        guarded = true;  // wave-uniform
       }
 #pragma unroll
       for (int k = 0; k < D; ++k) {
@@ -735,8 +754,10 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   // Measured at config 3 (f32, N = 262 144) and on the reference's matrix size (f64, N = 10^5), gpurun_out/r02/k2_times*.txt:
   // every variant with ONE pair chain per lane in flight runs at 24.05 ms (36.3 % of the FP32 vector peak) whatever NT, KS
   // and the occupancy (3 to 6 waves per SIMD); every variant that interleaves 2 or 4 chains runs at 28.7 ms — the interleaved
-  // order puts v_rsq_f32 and v_rcp_f32 back to back.  In f64 the forms differ by < 2 %; (8, 4, 4) is the fastest (7.47 ms).
-  int cfg = sizeof(T) == 4 ? 0 : 1;
+  // order puts v_rsq_f32 and v_rcp_f32 back to back.  f64 (N = 10^5, ms): with the guarded rsq+rcp weight everywhere (8, 4, 4) was
+  // the fastest at 7.47; with the reciprocal-free weight and a guarded second pass only for the blocks that held a near pair
+  // (see the kernel) (8, 8, 1) 6.79, (8, 4, 1) 6.95, (8, 4, 2) 7.00, (8, 2, 2) 7.01, (8, 2, 1) 7.26, (16, 8, 1) 8.03, (8, 4, 4) 9.96.
+  int cfg = sizeof(T) == 4 ? 0 : 5;
   if (const char* e = getenv("NBODY_K2_CFG")) cfg = atoi(e);  // experiments only (tools/time_collapsed.py)
 #define NB_K2(NT, KS, NBC)                                                                                              \
   hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, NT, KS, NBC>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,        \
@@ -746,6 +767,10 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
     case 0: NB_K2(16, 8, 1); break;
     case 1: NB_K2(8, 4, 4); break;
     case 2: NB_K2(8, 4, 1); break;
+    case 4: NB_K2(8, 4, 2); break;
+    case 5: NB_K2(8, 8, 1); break;
+    case 6: NB_K2(8, 2, 1); break;
+    case 7: NB_K2(8, 2, 2); break;
     default: NB_K2(16, 8, 4); break;
   }
 #undef NB_K2

@@ -245,6 +245,38 @@ __device__ __forceinline__ void pair_accumulate_multi(T (&acc)[D], const T (&xi)
   }
 }
 
+// K2 in f64: the same pairs with K1's reciprocal-free weight and NO per-chain branch (a near-pair branch in every chain makes
+// hipcc keep all chains' temporaries alive: 350 VGPRs).  The caller tracks the smallest high word of r2 it has seen and, if a
+// block of pairs held one below 2^-16 (a self pair, a very close body), discards that block's sums and recomputes them with the
+// guarded form (pair_accumulate_multi) — the far results of such a block may be inf/NaN and are never used.
+template <int D, int NB>
+__device__ __forceinline__ void pair_accumulate_far(double (&acc)[D], const double (&xi)[D], const src_rec<double, D>* s,
+                                                    uint32_t& lowest, double k15, double k1875) {
+  double d[NB][D], r2[NB], w[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[b][k] = s[b].p[k] - xi[k];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    r2[b] = pair_math<double>::tiny;
+#pragma unroll
+    for (int k = 0; k < D; ++k) r2[b] = __builtin_elementwise_fma(d[b][k], d[b][k], r2[b]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    w[b]              = pair_math<double>::weight_far(r2[b], s[b].m, k15, k1875);
+    const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[b]) >> 32);
+    lowest            = hi < lowest ? hi : lowest;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w[b], d[b][k], acc[k]);
+  }
+}
+
 // Loop-invariant operands of pair_batch that must stay in registers (made opaque to the optimiser once, outside the loop).
 template <typename T>
 struct pair_consts {

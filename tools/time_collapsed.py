@@ -4,7 +4,7 @@ import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 from conftest import load_package
 nb = load_package()
-CFG = {0: "(16,8,1)", 1: "(8,4,4)", 2: "(8,4,1)", 3: "(16,8,4)"}
+CFG = {0: "(16,8,1)", 1: "(8,4,4)", 2: "(8,4,1)", 3: "(16,8,4)", 4: "(8,4,2)", 5: "(8,8,1)", 6: "(8,2,1)", 7: "(8,2,2)"}
 for n, dtype, dim in ((262144, nb.F32, 3), (100000, nb.F64, 3), (100000, nb.F32, 3), (10000, nb.F32, 2)):
     dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, "uniform", n))
     runs = [("collapsed cfg %d %s" % (c, CFG[c]), dev.all_pairs_collapsed_force, str(c)) for c in sorted(CFG)] + [("all-pairs", dev.all_pairs_force, None)]

@@ -201,17 +201,44 @@ def launch_ranks(args):
            "--warmup", str(args.warmup), "--bodies", str(args.n)]
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    line = None
-    for out in proc.stdout:
-        txt = out.strip()
-        if txt.startswith("{") and '"metric"' in txt:
-            line = txt
-        elif txt:
-            print(txt, file=sys.stderr)
-    rc = proc.wait()
-    if line is not None:
-        print(line, flush=True)
+    if args.exchange != "nbody":
+        cmd += ["--exchange", args.exchange]
+    # The ranks run in their own process group under a wall-clock limit: a rank stuck in a collective (a peer that died
+    # before ncclCommInitRank, a lost link) must end as a non-zero exit of this command, not as a hang of the caller.
+    limit = float(os.environ.get("NBODY_BENCH_LAUNCH_TIMEOUT", "0")) or (600.0 + 3.0 * (args.steps + args.warmup) * (args.n / (1 << 20)) ** 2)
+    import signal
+    import threading
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    lines = []
+
+    def relay():
+        for out in proc.stdout:
+            txt = out.strip()
+            if txt.startswith("{") and '"metric"' in txt:
+                lines.append(txt)
+            elif txt:
+                print(txt, file=sys.stderr)
+
+    reader = threading.Thread(target=relay, daemon=True)
+    reader.start()
+    try:
+        rc = proc.wait(timeout=limit)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the ranks did not finish within {limit:.0f} s (NBODY_BENCH_LAUNCH_TIMEOUT): killing them", file=sys.stderr)
+        for sig in (signal.SIGTERM, signal.SIGKILL):
+            try:
+                os.killpg(proc.pid, sig)   # the exact process group started above
+            except ProcessLookupError:
+                break
+            try:
+                proc.wait(timeout=10)
+                break
+            except subprocess.TimeoutExpired:
+                continue
+        raise SystemExit(124)
+    reader.join(timeout=10)
+    if rc == 0 and lines:
+        print(lines[-1], flush=True)
     elif rc == 0:
         rc = 1
         print("bench.py: the ranks exited without printing a result line", file=sys.stderr)
@@ -226,6 +253,10 @@ def main():
     ap.add_argument("--bodies", dest="n", type=int, default=1 << 20,
                     help="bodies (default 2^20, the BASELINE.json metric config); `--n` would collide with torchrun option prefixes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=("nbody", "torch"), default="nbody",
+                    help="the per-step all-gather of positions: nbody = the library's own collective (nbody_allgather_positions, "
+                         "RCCL behind the C ABI; what the metric is about, and the only form that earns a normal line); torch = "
+                         "torch.distributed's all_gather, for A/B runs only — the line is marked")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -277,35 +308,65 @@ def main():
     nb = load_package()
     par = nb.parallel
 
-    # the data-path collective is the library's own (nbody_allgather_positions, RCCL behind the C ABI); torch.distributed
-    # is the launcher's side: it carries the RCCL unique id to the ranks, the barriers and the max-over-ranks of the time
+    # Fault injection for the tests of the failure exits below (tests/test_gpu_multi.py): "<kind>:<rank>" with kind in
+    # comm_create (the communicator cannot be created on that rank), stale_exchange (that rank's exchange delivers nothing from
+    # the start: it takes part in the collective and throws the result away), stale_late (… from the first timed step on: only
+    # the end-of-run checks can see it), corrupt_a (one acceleration row of that rank is altered before the bitwise check).
+    fault_kind, _, fault_rank = os.environ.get("NBODY_BENCH_FAULT", "").partition(":")
+    fault = fault_kind if fault_kind and int(fault_rank or 0) == rank else None
+
+    def fail_all(reason):
+        """Every rank leaves with a non-zero status and the reason on stderr; no result line is printed."""
+        print(f"bench.py: rank {rank}: {reason}", file=sys.stderr, flush=True)
+        sys.stderr.flush()
+        os._exit(3)   # every rank reaches the same verdict (the checks are collective), so nobody is left in a collective
+
+    # The data-path collective is the library's own (nbody_allgather_positions, RCCL behind the C ABI); torch.distributed is the
+    # launcher's side: it carries the RCCL unique id to the ranks, the barriers and the max-over-ranks of the time.  If the
+    # communicator cannot be created, or its exchange fails a cross-rank check, THE RUN FAILS (non-zero exit, no line): a line
+    # from another exchange would credit a collective that did not work.  `--exchange torch` selects torch.distributed's
+    # all_gather explicitly, and the line says so.
     comm, comm_note = None, None
     if share_gpu:
         comm_note = "REHEARSAL: %d ranks share one GPU, gloo group, shards staged through the host" % world
+    elif use_dist and args.exchange == "torch":
+        comm_note = "--exchange torch: torch.distributed all_gather over padded shards (NOT the library's collective)"
     elif use_dist:
-        # Every rank must end up on the same exchange: if the communicator cannot be created on ANY rank (RCCL not loadable
-        # through dlopen, a version clash with the copy PyTorch mapped), all ranks use the torch.distributed form of the
-        # same all-gather (still RCCL) and the line says so.
-        ok, err = 1, ""
+        # 1. vote BEFORE any rank enters the collective ncclCommInitRank: a rank that cannot load RCCL or has no device would
+        #    otherwise leave the others blocked in it
+        err = ""
         try:
-            box = [nb.Comm.unique_id() if rank == 0 else None]
+            ok = 1 if nb.Comm.rccl_version() > 0 else 0
+            if not ok:
+                err = "RCCL cannot be loaded (nbody_comm_rccl_version() == 0): " + nb.lib().nbody_last_error().decode()
+            nb.device_info(local_rank)
         except Exception as ex:
-            box, ok, err = [None], 0, str(ex)
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            ok = 0
-        if ok:
-            try:
-                comm = nb.Comm(world, rank, box[0], local_rank)
-            except Exception as ex:
-                ok, err = 0, str(ex)
+            ok, err = 0, str(ex)
+        if fault == "comm_create":
+            ok, err = 0, "injected fault: communicator creation refused on this rank"
         flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
-            if comm is not None:
-                comm.close()
-            comm, comm_note = None, "nbody_comm unavailable on some rank (%s): torch.distributed all_gather instead" % (err or "another rank")
-            print("bench.py: " + comm_note, file=sys.stderr)
+            fail_all("nbody_comm cannot be created on every rank (%s); no fallback — use --exchange torch to run without it"
+                     % (err or "another rank reported the failure"))
+        # 2. the unique id, from rank 0 to everybody
+        try:
+            box = [nb.Comm.unique_id() if rank == 0 else None]
+        except Exception as ex:
+            box, err = [None], str(ex)
+        dist.broadcast_object_list(box, src=0)
+        if box[0] is None:
+            fail_all("nbody_comm_get_unique_id failed on rank 0 (%s)" % (err or "see rank 0"))
+        # 3. the collective creation, then a second vote on its outcome
+        try:
+            comm = nb.Comm(world, rank, box[0], local_rank)
+            ok = 1
+        except Exception as ex:
+            ok, err = 0, str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            fail_all("nbody_comm_create failed (%s)" % (err or "on another rank"))
 
     # synthetic galaxy init with the product's host generator (host/models.hpp == src/models.h:112-136)
     hs = nb.build_model(nb.F64, 3, "galaxy", args.n)
@@ -313,37 +374,39 @@ def main():
     sim = par.ShardedAllPairs(hs, rank, world, torch_device=dev, force_exchange=use_dist, comm=comm)
     kernel_desc = nb.describe_all_pairs(sim.state())
 
+    if fault in ("stale_exchange", "stale_late"):
+        real_exchange = sim.exchange_positions
+
+        def stale_exchange():   # takes part in the collective (nobody hangs), then puts the other ranks' old rows back
+            keep = sim.x.clone()
+            real_exchange()
+            keep[sim.first:sim.first + sim.count] = sim.x[sim.first:sim.first + sim.count]
+            sim.x.copy_(keep)
+
+        if fault == "stale_exchange":
+            sim.exchange_positions = stale_exchange
+
+    def ranks_agree():
+        """Two checksums of the full x, compared across the ranks (min == max): a rank whose exchange did not deliver keeps
+        stale rows, and every number below would mean nothing."""
+        wts = torch.arange(1, sim.x.numel() + 1, dtype=torch.float64, device=dev).reshape(sim.x.shape)
+        sums = torch.stack([sim.x.sum(dtype=torch.float64), (sim.x * wts).sum(dtype=torch.float64)]).to(red_dev)
+        lo, hi = sums.clone(), sums.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        return torch.equal(lo, hi), sums
+
     for _ in range(max(args.warmup, 1) if use_dist else args.warmup):
         sim.step()
     exchange_check = None
     if use_dist:
-        # after a step every rank must hold the same positions: two checksums of the full x, compared across the ranks
-        # (a rank whose exchange did not deliver would keep stale rows, and the number below would mean nothing)
-        wts = torch.arange(1, sim.x.numel() + 1, dtype=torch.float64, device=dev).reshape(sim.x.shape)
-
-        def ranks_agree():
-            sums = torch.stack([sim.x.sum(), (sim.x * wts).sum()]).to(red_dev)
-            lo, hi = sums.clone(), sums.clone()
-            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-            return torch.equal(lo, hi), sums
-
-        same, sums = ranks_agree()
-        if not same and comm is not None:
-            # the library's exchange did not leave every rank with the same x: redo it with torch.distributed's all_gather
-            # (every rank's own rows are intact) and stay on that form; the line says so
-            comm_note = "nbody_allgather_positions failed the cross-rank check: torch.distributed all_gather instead"
-            print("bench.py: " + comm_note, file=sys.stderr)
-            comm.close()
-            comm = None
-            sim.use_torch_exchange()
-            sim.exchange_positions()
-            same, sums = ranks_agree()
+        same, sums = ranks_agree()   # collective: every rank takes the same branch
         if not same:
-            raise SystemExit(f"rank {rank}: positions differ between ranks after the exchange (checksums {sums.tolist()})")
-        exchange_check = "full x identical on all %d rank(s) after the warm-up exchange (2 checksums, min == max over ranks)" % world
-        del wts
+            fail_all("positions differ between ranks after the warm-up exchange (%s; this rank's checksums %s): the run is void"
+                     % (sim.describe().split("exchange: ")[-1], sums.tolist()))
         dist.barrier()
+    if fault == "stale_late":
+        sim.exchange_positions = stale_exchange
     torch.cuda.synchronize()
     telemetry = Telemetry(local_rank) if rank == 0 else None
     if telemetry:
@@ -373,6 +436,59 @@ def main():
     flops_per_launch = FLOP_PER_INTERACTION * sim.count * (n - 1)
     achieved = flops_per_launch / (k1_ms * 1e-3) / 1e12 if k1_ms > 0 else 0.0
 
+    # ---- after the clock has stopped: the multi-rank run verifies itself -------------------------------------------------
+    per_rank, bitwise = None, None
+    if use_dist:
+        # (a) every rank still holds the same x after the LAST exchange
+        same, sums = ranks_agree()
+        if not same:
+            fail_all("positions differ between ranks after the timed steps (this rank's checksums %s): the run is void" % sums.tolist())
+        exchange_check = ("full x identical on all %d rank(s) after the warm-up exchange and after the last timed step "
+                          "(2 checksums, min == max over ranks)" % world)
+        # (b) per-rank kernel and exchange times (HIP events on the launching stream)
+        mine = torch.tensor([k1_ms, xchg_ms], dtype=torch.float64, device=red_dev)
+        allt = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allt, mine)
+        k1s, xgs = [float(t[0]) for t in allt], [float(t[1]) for t in allt]
+        per_rank = {"k1_ms": {"min": min(k1s), "max": max(k1s), "by_rank": k1s},
+                    "allgather_ms": {"min": min(xgs), "max": max(xgs), "by_rank": xgs}}
+        # (c) bitwise_vs_single: the design guarantees that a target's sum does not depend on the shard window or the world
+        # size.  Every rank recomputes K1 on its shard from the positions it holds NOW (no K3), then rank 0 computes a window of
+        # WIN targets in the middle of each rank's shard from ITS OWN x and compares with that rank's rows, bit for bit.
+        WIN = 4096
+        sim.force_phase()
+        torch.cuda.synchronize()
+        if fault == "corrupt_a":
+            sim.a[sim.count // 2] += 1e-9
+        scratch = torch.empty((WIN, 3), dtype=sim.a.dtype, device=dev)
+        checked, mismatch = [], []
+        for p, (pf, pe) in enumerate(sim.shards):
+            cnt = min(WIN, pe - pf)
+            off = (pe - pf - cnt) // 2
+            rows = torch.zeros((WIN, 3), dtype=sim.a.dtype, device=red_dev)
+            if rank == p:
+                rows[:cnt] = sim.a[off:off + cnt].to(red_dev)
+            dist.broadcast(rows, src=p)
+            if rank == 0 and cnt > 0:
+                st = sim.state()
+                st.first, st.count = pf + off, cnt
+                st.a = st.v = st.ao = scratch.data_ptr()   # K1 writes a only; v/ao are not touched by it
+                rc = nb.lib().nbody_all_pairs_force(C.byref(st), C.c_void_p(sim._stream()))
+                if rc:
+                    fail_all("bitwise_vs_single: K1 on the window failed: " + nb.lib().nbody_last_error().decode())
+                torch.cuda.synchronize()
+                checked.append(p)
+                if not torch.equal(scratch[:cnt].to(red_dev), rows[:cnt]):
+                    mismatch.append(p)
+        verdict = torch.tensor([len(mismatch)], dtype=torch.int32, device=red_dev)
+        dist.broadcast(verdict, src=0)
+        if int(verdict.item()) != 0:
+            fail_all("bitwise_vs_single failed: rank 0's K1 on a %d-target window of rank(s) %s differs from the rows those ranks "
+                     "computed (stale positions on a rank, or a window-dependent sum): the run is void" % (WIN, mismatch if rank == 0 else "?"))
+        bitwise = {"equal": True, "checked_ranks": checked, "targets_per_window": WIN,
+                   "how": "after the timed steps every rank recomputed K1 on its shard; rank 0 recomputed a window in the middle of "
+                          "each rank's shard from its own x and compared the rows bit for bit"}
+
     if rank == 0:
         value = n * args.steps / elapsed
         whole_job_tflops = FLOP_PER_INTERACTION * n * (n - 1) * args.steps / elapsed / 1e12
@@ -382,6 +498,7 @@ def main():
         out = {
             "metric": "body-steps/sec + %FP64 peak, 3D double all-pairs N=2^20 at 1/2/4/8 GPUs",
             **({"rehearsal": comm_note} if share_gpu else {}),
+            **({"not_the_library_collective": comm_note} if (use_dist and not share_gpu and comm is None) else {}),
             "value": value, "unit": "body-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -392,7 +509,8 @@ def main():
             "rccl_world": ({"world": dist.get_world_size(), "backend": dist.get_backend(),
                             "data_path": ("nbody_comm (ncclCommInitRank) world %d, RCCL %d" % (comm.world, nb.Comm.rccl_version())
                                           if comm is not None else comm_note),
-                            "exchange_check": exchange_check}
+                            "exchange": "nbody" if comm is not None else ("rehearsal" if share_gpu else args.exchange),
+                            "exchange_check": exchange_check, "bitwise_vs_single": bitwise, "per_rank": per_rank}
                            if use_dist else None),
             "shards": [e - f for f, e in sim.shards],
             "allgather": {"sent_bytes_per_rank_per_step": sim.count * row, "gathered_bytes_per_step": n * row,

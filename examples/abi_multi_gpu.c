@@ -23,7 +23,8 @@
 
 int main(int argc, char** argv) {
   const int ngpus  = argc > 1 ? atoi(argv[1]) : 1;
-  const uint32_t n = 5003; /* not a multiple of 2, 3, 4 or 8: uneven shards take the grouped send/recv path */
+  /* default 5003: not a multiple of 2, 3, 4 or 8, so uneven shards take the grouped send/recv path; argv[2] overrides */
+  const uint32_t n = argc > 2 ? (uint32_t)atoi(argv[2]) : 5003u;
   const int steps  = 3;
   if (ngpus < 1 || ngpus > MAXG) return 2;
   double *m = malloc(sizeof(double) * n), *x = malloc(sizeof(double) * 3 * n), *v = calloc(3 * n, sizeof(double)),

@@ -22,7 +22,8 @@
  *    Single GPU: first = 0, count = sz.
  *  - The library never falls back to a CPU path: without a usable HIP device every call fails.
  *  - Devices: a context, a tree and a communicator remember the device they were created on; a phase call runs on
- *    the device of its `stream` (NULL stream: the calling thread's current device).  Every entry point switches to
+ *    the device of its `stream` (NULL stream: the calling thread's current device); a tree must be used with a stream
+ *    of its own device (NBODY_ERR_ARG otherwise).  Every entry point switches to
  *    that device for the duration of the call and restores the caller's, so one host thread can drive several GPUs.
  */
 #ifndef NBODY_HIP_H
@@ -59,7 +60,8 @@ typedef struct nbody_state {
   int32_t dim;     /* 2 | 3                                                         */
   uint32_t tuning; /* K1 launch shape for calls with this view: 0 = the library default, else
                       NBODY_TUNING(split, targets_per_thread, source_path); never changes which
-                      pairs are summed (see nbody_all_pairs_configure)              */
+                      pairs are summed (see nbody_all_pairs_configure).  A state filled by hand
+                      must zero this field: any other value is refused (NBODY_ERR_ARG)       */
 } nbody_state;
 
 /* split in bits 0-3, targets per lane in bits 4-5, source path in bits 6-7; each 0 = auto */
@@ -67,8 +69,10 @@ typedef struct nbody_state {
   ((uint32_t)(((split) & 15) | (((targets_per_thread) & 3) << 4) | (((source_path) & 3) << 6) | 0x100u))
 
 /* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major.
- * 2.0: nbody_state.tuning; the collective (nbody_comm_*), shard windows on contexts, per-device guards. */
-#define NBODY_HIP_ABI_VERSION 2000
+ * 2.0: nbody_state.tuning; the collective (nbody_comm_*), shard windows on contexts, per-device guards.
+ * 2.1: nbody_bvh_create_on / nbody_octree_create_on (explicit device), nbody_octree_set_walk, nbody_bvh_set_launch_order;
+ *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)). */
+#define NBODY_HIP_ABI_VERSION 2001
 int nbody_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -119,7 +123,8 @@ int nbody_all_pairs_source_path(int mode);
 /* Tree + scratch storage; replaces bvh<T,N>::alloc / dealloc (src/bvh.h:147-172).
  * nleafs = bit_ceil(n), nlevels = log2(nleafs), nnodes = 2^nlevels - 1.  n >= 2. */
 typedef struct nbody_bvh nbody_bvh;
-int  nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n);
+int  nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n);               /* on the current device */
+int  nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t n, int device); /* device < 0: the current one */
 void nbody_bvh_destroy(nbody_bvh* t);
 
 /* K4. Replaces bounding_box (src/bvh.h:17-22): AABB of all x padded by +-10 eps, always containing
@@ -153,6 +158,9 @@ int nbody_bvh_enable_counters(nbody_bvh* t, int on);
  * program with 1 / 2 bodies per lane; 5: the step program written out as ISA — what 0 and 2 use).  All forms make
  * every body perform the same tests in the same order: results and counters are bitwise identical. */
 int nbody_bvh_set_traversal(nbody_bvh* t, int mode);
+/* Launch order of the sweep: 0 = work items (groups that straddle a jump of the key order are cut in two and start first),
+ * 1 = one block per group in index order.  Bitwise identical results; tests and tuning runs compare the two. */
+int nbody_bvh_set_launch_order(nbody_bvh* t, int mode);
 uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
 
 /* ---- octree Barnes-Hut (src/octree.h, the reference's default --algorithm) ---------------------------------
@@ -162,8 +170,12 @@ uint32_t nbody_bvh_nnodes(const nbody_bvh* t);
  * honours the shard window.  Errors found on the device (coincident bodies / node pool exhausted) surface in nbody_octree_info. */
 typedef struct nbody_octree nbody_octree;
 /* octree<T,N>::alloc / dealloc (src/octree.h:42-60); capacity = max(2^dim * n, 1000) nodes (src/system.h:30). */
-int  nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n);
+int  nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n);               /* on the current device */
+int  nbody_octree_create_on(nbody_octree** out, int dtype, int dim, uint32_t n, int device); /* device < 0: the current one */
 void nbody_octree_destroy(nbody_octree* t);
+/* Scheduling form of the walk: 0 = auto, 1 = the compiler-scheduled kernel, 2 = the visit round written as ISA (fails where that
+ * form does not exist).  Same tests, same arithmetic, same order: bitwise identical accelerations and counters. */
+int  nbody_octree_set_walk(nbody_octree* t, int mode);
 /* octree::clear (src/octree.h:85-89): readies the tree for the next step. */
 int nbody_octree_clear(nbody_octree* t, void* stream);
 /* octree::compute_bounds (src/octree.h:93-112): root cube from the scalar min/max over all coordinates, +-1. */

@@ -49,6 +49,7 @@ ABI_SYMBOLS = [
     "nbody_octree_create", "nbody_octree_destroy", "nbody_octree_clear", "nbody_octree_compute_bounds", "nbody_octree_insert",
     "nbody_octree_compute_tree", "nbody_octree_compute_force", "nbody_octree_info", "nbody_octree_enable_counters",
     "nbody_octree_read_counters", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
+    "nbody_bvh_create_on", "nbody_octree_create_on", "nbody_octree_set_walk", "nbody_bvh_set_launch_order",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
     "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
     "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
@@ -217,10 +218,11 @@ def build_model(dtype, dim, workload, n):
 class Bvh:
     """bvh<T,N> (src/bvh.h:98-325) on the device."""
 
-    def __init__(self, dtype, dim, n):
+    def __init__(self, dtype, dim, n, device=-1):
+        """device: where the tree's buffers live (-1: the calling thread's current device)."""
         self.h = C.c_void_p()
         self.dtype, self.dim, self.n = dtype, dim, n
-        _check(lib().nbody_bvh_create(C.byref(self.h), dtype, dim, C.c_uint32(n)))
+        _check(lib().nbody_bvh_create_on(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
         self.nnodes = int(lib().nbody_bvh_nnodes(self.h))
 
     def close(self):
@@ -256,6 +258,10 @@ class Bvh:
         """0 auto, 1 per-lane walks, 2 wave-cooperative sweep (bitwise identical results)."""
         _check(lib().nbody_bvh_set_traversal(self.h, mode))
 
+    def set_launch_order(self, mode):
+        """Sweep: 0 work items (cut groups first), 1 one block per group in index order (bitwise identical results)."""
+        _check(lib().nbody_bvh_set_launch_order(self.h, mode))
+
     def enable_counters(self, on=True):
         _check(lib().nbody_bvh_enable_counters(self.h, 1 if on else 0))
 
@@ -272,10 +278,15 @@ class Bvh:
 class Octree:
     """octree<T,N> (src/octree.h) on the device."""
 
-    def __init__(self, dtype, dim, n):
+    def __init__(self, dtype, dim, n, device=-1):
+        """device: where the tree's buffers live (-1: the calling thread's current device)."""
         self.h = C.c_void_p()
         self.dtype, self.dim, self.n = dtype, dim, n
-        _check(lib().nbody_octree_create(C.byref(self.h), dtype, dim, C.c_uint32(n)))
+        _check(lib().nbody_octree_create_on(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
+
+    def set_walk(self, mode):
+        """0 auto, 1 the compiler-scheduled walk kernel, 2 the visit round as ISA (bitwise identical results)."""
+        _check(lib().nbody_octree_set_walk(self.h, mode))
 
     def close(self):
         if self.h:
@@ -324,7 +335,7 @@ class DeviceSystem:
 
     def __init__(self, dtype, dim, n, device=0):
         self.h = C.c_void_p()
-        self.dtype, self.dim, self.n = dtype, dim, n
+        self.dtype, self.dim, self.n, self.device = dtype, dim, n, device
         _check(lib().nbody_create(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
         self.stream = lib().nbody_ctx_stream(self.h)
         self._bvh = None
@@ -413,13 +424,13 @@ class DeviceSystem:
     @property
     def bvh(self):
         if self._bvh is None:
-            self._bvh = Bvh(self.dtype, self.dim, self.n)
+            self._bvh = Bvh(self.dtype, self.dim, self.n, self.device)
         return self._bvh
 
     @property
     def octree(self):
         if self._octree is None:
-            self._octree = Octree(self.dtype, self.dim, self.n)
+            self._octree = Octree(self.dtype, self.dim, self.n, self.device)
         return self._octree
 
     def octree_force(self, theta):

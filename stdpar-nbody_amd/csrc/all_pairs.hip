@@ -400,7 +400,7 @@ static int plan_all_pairs(const nbody_state* s, k1_plan* out) {
   // its single-chunk order) and only in the scalar-stream form
   p.tiles_per_chunk = (s->sz + kTileJ - 1) / kTileJ;
   if (p.scalar && cfg.split == 0 && p.js == 8) ap_auto_chunks(s->sz, &p.chunks, &p.tiles_per_chunk);
-  if (const char* e = getenv("NBODY_K1_CHUNKS"); e && p.scalar) {  // experiments only (tools/tune_all_pairs.py): changes the rounding order
+  if (const char* e = experiment_env("NBODY_K1_CHUNKS"); e && p.scalar) {  // -DNBODY_EXPERIMENTS builds only (tools/tune_chunks.py): changes the rounding order
     const uint32_t ntiles = (s->sz + kTileJ - 1) / kTileJ;
     uint32_t y            = uint32_t(atoi(e));
     if (y >= 1 && y <= ntiles) {
@@ -758,7 +758,7 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   // the fastest at 7.47; with the reciprocal-free weight and a guarded second pass only for the blocks that held a near pair
   // (see the kernel) (8, 8, 1) 6.79, (8, 4, 1) 6.95, (8, 4, 2) 7.00, (8, 2, 2) 7.01, (8, 2, 1) 7.26, (16, 8, 1) 8.03, (8, 4, 4) 9.96.
   int cfg = sizeof(T) == 4 ? 0 : 5;
-  if (const char* e = getenv("NBODY_K2_CFG")) cfg = atoi(e);  // experiments only (tools/time_collapsed.py)
+  if (const char* e = experiment_env("NBODY_K2_CFG")) cfg = atoi(e);  // -DNBODY_EXPERIMENTS builds only (tools/time_collapsed.py)
 #define NB_K2(NT, KS, NBC)                                                                                              \
   hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, NT, KS, NBC>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,        \
                      static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), \

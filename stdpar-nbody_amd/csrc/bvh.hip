@@ -42,7 +42,7 @@ struct alignas(sizeof(T) * 8) tree_rec {
 }  // namespace nbody
 
 struct nbody_bvh {
-  int dtype = 0, dim = 0, device = 0;  // device: the one current at nbody_bvh_create; every call runs there
+  int dtype = 0, dim = 0, device = 0;  // device: nbody_bvh_create_on's (nbody_bvh_create: the current one); every call runs there
   uint32_t n = 0, nlevels = 0, nnodes = 0;
   size_t tsz = 0, rec_bytes = 0;
   uint32_t sort_blocks = 0, bbox_blocks = 0;
@@ -59,6 +59,7 @@ struct nbody_bvh {
   uint32_t* order_n = nullptr;  // items per list
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
+  int launch_order = 0; // sweep: 0 = work items (cut groups first), 1 = one block per group in index order
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
 };
 
@@ -1191,9 +1192,10 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-static int check_tree(const nbody_bvh* t, const nbody_state* s, bool need_full) {
+static int check_tree(const nbody_bvh* t, const nbody_state* s, bool need_full, void* stream) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
   if (int r = check_state(s)) return r;
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_bvh")) return r;
   NB_ARG(t->dtype == s->dtype && t->dim == s->dim && t->n == s->sz, "bvh was created for (dtype=%d, dim=%d, n=%u), state is (%d, %d, %u)",
          t->dtype, t->dim, t->n, s->dtype, s->dim, s->sz);
   if (need_full) NB_ARG(s->first == 0 && s->count == s->sz, "this bvh phase needs the whole system (first=0, count=sz)");
@@ -1277,7 +1279,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // sweep by 25-40 % (whole 1000-step runs, sweep / per-lane: 0.86 / 0.91 s at 10^4, 0.99 / 1.07 at 2*10^4, 1.16 / 1.47 at 3*10^4)
   const uint32_t crossover = sizeof(T) == 8 ? 30000u : 180000u;
   int traversal = t->traversal;
-  if (const char* e = getenv("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // experiments only
+  if (const char* e = experiment_env("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // -DNBODY_EXPERIMENTS builds only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
@@ -1297,8 +1299,8 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
    s->count, th2, t->nlevels, t->counters
   const uint32_t *items = nullptr, *nitems = nullptr;
   uint32_t stride = 0, wave_blocks = blocks;
-  const char* oe = getenv("NBODY_K9_ORDER");  // experiments: 0 = one block per group in index order
-  if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && !(oe && oe[0] == '0')) {
+  const char* oe = experiment_env("NBODY_K9_ORDER");  // -DNBODY_EXPERIMENTS builds: 0 = one block per group in index order
+  if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && t->launch_order == 0 && !(oe && oe[0] == '0')) {
     // Work items (bvh_items_kernel): groups that straddle a jump of the key order are cut in two and start first.  Measured
     // in the CLI's step loop (ms per whole bvh step; index order / start order only / start order + cut): N = 10^6 8.05 / 7.4 /
     // 7.4, 5*10^5 5.3 / 4.6 / 4.3.  The sorted keys are in keys[1] (8 radix passes end in the buffer they started from).
@@ -1312,7 +1314,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     items  = t->order;
     nitems = t->order_n;
   }
-  const char* le = getenv("NBODY_K9_LDS");  // experiments: dynamic LDS bytes per block, to cap the waves per SIMD
+  const char* le = experiment_env("NBODY_K9_LDS");  // -DNBODY_EXPERIMENTS builds: dynamic LDS bytes per block, to cap the waves per SIMD
   const uint32_t lds = le ? uint32_t(atoi(le)) : 0u;
 #define NB_WARGS                                                                                                             \
   dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
@@ -1342,13 +1344,22 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 using namespace nbody;
 
 extern "C" int nbody_bvh_create(nbody_bvh** out, int dtype, int dim, uint32_t n) {
+  return nbody_bvh_create_on(out, dtype, dim, n, -1);
+}
+
+extern "C" int nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t n, int device) {
   NB_ARG(out != nullptr, "out is NULL");
   *out = nullptr;
   NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
   NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
   NB_ARG(n >= 2 && n <= (1u << 30), "bvh needs 2 <= n <= 2^30 (got %u)", n);
+  int ndev = 0;
+  NB_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0) device = current_device();
+  NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
+  device_guard guard(device);
   auto* t  = new nbody_bvh;
-  t->device = current_device();
+  t->device = device;
   t->dtype = dtype;
   t->dim   = dim;
   t->n     = n;
@@ -1431,8 +1442,15 @@ extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   return NBODY_OK;
 }
 
+extern "C" int nbody_bvh_set_launch_order(nbody_bvh* t, int mode) {
+  NB_ARG(t != nullptr, "nbody_bvh is NULL");
+  NB_ARG(mode == 0 || mode == 1, "launch order must be 0 (work items) or 1 (index order), got %d", mode);
+  t->launch_order = mode;
+  return NBODY_OK;
+}
+
 extern "C" int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* stream) {
-  if (int r = check_tree(t, s, false)) return r;
+  if (int r = check_tree(t, s, false, stream)) return r;
   device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
@@ -1458,7 +1476,7 @@ extern "C" int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xm
 }
 
 extern "C" int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* stream) {
-  if (int r = check_tree(t, s, true)) return r;
+  if (int r = check_tree(t, s, true, stream)) return r;
   device_guard guard(t->device);
   if (!t->have_bbox) {
     set_error("nbody_bvh_hilbert_sort before nbody_bvh_bounding_box");
@@ -1473,7 +1491,7 @@ extern "C" int nbody_bvh_hilbert_sort(nbody_bvh* t, const nbody_state* s, void* 
 }
 
 extern "C" int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* stream) {
-  if (int r = check_tree(t, s, false)) return r;
+  if (int r = check_tree(t, s, false, stream)) return r;
   device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
@@ -1484,7 +1502,7 @@ extern "C" int nbody_bvh_build_tree(nbody_bvh* t, const nbody_state* s, void* st
 }
 
 extern "C" int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, double theta, void* stream) {
-  if (int r = check_tree(t, s, false)) return r;
+  if (int r = check_tree(t, s, false, stream)) return r;
   device_guard guard(t->device);
   if (!t->built) {
     set_error("nbody_bvh_compute_force before nbody_bvh_build_tree");

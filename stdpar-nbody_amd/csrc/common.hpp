@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/nbody_hip.h"
@@ -59,6 +60,24 @@ inline int stream_device(hipStream_t st) {
   return hipStreamGetDevice(st, &d) == hipSuccess ? int(d) : current_device();
 }
 
+// a handle (context, tree, communicator) is used on the device it was created on: its buffers live there
+inline int check_same_device(int handle_device, hipStream_t st, const char* what) {
+  const int sd = stream_device(st);
+  NB_ARG(handle_device == sd, "%s was created on device %d but the call's stream belongs to device %d", what, handle_device, sd);
+  return NBODY_OK;
+}
+
+// Experiment switches (tools/README.md) exist only in the build made with -DNBODY_EXPERIMENTS (`make experiments`:
+// libnbody_hip_exp.so); the shipped library never reads the environment — the launch shape is what nbody_all_pairs_describe
+// states and what the ABI setters select.
+#ifdef NBODY_EXPERIMENTS
+inline const char* experiment_env(const char* name) { return getenv(name); }
+#else
+constexpr const char* experiment_env(const char*) { return nullptr; }
+#endif
+
+inline int check_tuning(int split, int tpt, int path);
+
 inline int check_state(const nbody_state* s) {
   NB_ARG(s != nullptr, "nbody_state is NULL");
   NB_ARG(s->dtype == NBODY_F32 || s->dtype == NBODY_F64, "bad dtype %d", s->dtype);
@@ -66,6 +85,12 @@ inline int check_state(const nbody_state* s) {
   NB_ARG(s->m && s->x && s->v && s->a && s->ao, "nbody_state has a NULL array pointer");
   NB_ARG(uint64_t(s->first) + uint64_t(s->count) <= uint64_t(s->sz), "shard [%u, %u+%u) exceeds sz=%u", s->first, s->first,
          s->count, s->sz);
+  // tuning is 0 or a value NBODY_TUNING() made: a hand-built state that was not zero-initialised is refused, not obeyed
+  if (s->tuning != 0) {
+    NB_ARG((s->tuning & ~0x1ffu) == 0 && (s->tuning & 0x100u) != 0, "nbody_state.tuning = 0x%x is not 0 or an NBODY_TUNING(...) value",
+           s->tuning);
+    if (int r = check_tuning(int(s->tuning & 15u), int((s->tuning >> 4) & 3u), int((s->tuning >> 6) & 3u))) return r;
+  }
   return NBODY_OK;
 }
 

@@ -1138,7 +1138,8 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
 
 // ---- host side / C ABI -----------------------------------------------------------------------------------------------
 struct nbody_octree {
-  int dtype = 0, dim = 0, device = 0;  // device: the one current at nbody_octree_create; every call runs there
+  int dtype = 0, dim = 0, device = 0;  // device: nbody_octree_create_on's (nbody_octree_create: the current one); every call runs there
+  int walk = 0;                        // nbody_octree_set_walk: 0 auto, 1 compiler-scheduled kernel, 2 the visit round as ISA
   uint32_t n = 0, capacity = 0, max_cells = 0, bounds_blocks = 0;
   size_t tsz = 0;
   void* root       = nullptr;  // T[D+1]: root_x (D), root_side_length
@@ -1160,9 +1161,10 @@ using namespace nbody;
 
 namespace nbody {
 
-static int ot_check(const nbody_octree* t, const nbody_state* s) {
+static int ot_check(const nbody_octree* t, const nbody_state* s, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
   if (int r = check_state(s)) return r;
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_octree")) return r;
   NB_ARG(t->dtype == s->dtype && t->dim == s->dim && t->n == s->sz,
          "octree was created for (dtype=%d, dim=%d, n=%u), state is (%d, %d, %u)", t->dtype, t->dim, t->n, s->dtype, s->dim, s->sz);
   return NBODY_OK;
@@ -1251,11 +1253,15 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
                      static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root),                                   \
                      t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
   // double, 3D: the visit round written as ISA (ot_force_isa_kernel), while 32-bit group offsets reach the whole array;
-  // NBODY_OT_FORM=1 keeps the compiler-scheduled kernel (tests compare the two bitwise)
+  // nbody_octree_set_walk(t, 1) keeps the compiler-scheduled kernel (tests compare the two bitwise)
   bool isa = false;
   if constexpr (sizeof(T) == 8 && D == 3) {
-    const char* fe = getenv("NBODY_OT_FORM");
-    isa            = !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32);
+    const char* fe = experiment_env("NBODY_OT_FORM");  // -DNBODY_EXPERIMENTS builds only
+    isa            = t->walk != 1 && !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32);
+  }
+  if (t->walk == 2 && !isa) {
+    set_error("octree walk: the ISA visit round exists for double 3D (and trees within 32-bit group offsets) only");
+    return NBODY_ERR_ARG;
   }
   if (isa) {
     if constexpr (sizeof(T) == 8 && D == 3) {
@@ -1278,13 +1284,29 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
 }  // namespace nbody
 
 extern "C" int nbody_octree_create(nbody_octree** out, int dtype, int dim, uint32_t n) {
+  return nbody_octree_create_on(out, dtype, dim, n, -1);
+}
+
+extern "C" int nbody_octree_set_walk(nbody_octree* t, int mode) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  NB_ARG(mode >= 0 && mode <= 2, "walk form must be 0 (auto), 1 (compiler-scheduled) or 2 (visit round as ISA), got %d", mode);
+  t->walk = mode;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, uint32_t n, int device) {
   NB_ARG(out != nullptr, "out is NULL");
   *out = nullptr;
   NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
   NB_ARG(dim == 2 || dim == 3, "bad dim %d", dim);
   NB_ARG(n >= 1 && n <= (1u << 28), "octree needs 1 <= n <= 2^28 (got %u)", n);
+  int ndev = 0;
+  NB_HIP(hipGetDeviceCount(&ndev));
+  if (device < 0) device = current_device();
+  NB_ARG(device >= 0 && device < ndev, "device %d out of range (%d HIP devices visible)", device, ndev);
+  device_guard guard(device);
   auto* t  = new nbody_octree;
-  t->device = current_device();
+  t->device = device;
   t->dtype = dtype;
   t->dim   = dim;
   t->n     = n;
@@ -1352,7 +1374,7 @@ extern "C" int nbody_octree_clear(nbody_octree* t, void* stream) {
 }
 
 extern "C" int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s, void* stream) {
-  if (int r = ot_check(t, s)) return r;
+  if (int r = ot_check(t, s, stream)) return r;
   device_guard guard(t->device);
   int r = dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
@@ -1363,7 +1385,7 @@ extern "C" int nbody_octree_compute_bounds(nbody_octree* t, const nbody_state* s
 }
 
 extern "C" int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* stream) {
-  if (int r = ot_check(t, s)) return r;
+  if (int r = ot_check(t, s, stream)) return r;
   device_guard guard(t->device);
   if (!t->have_bounds) {
     set_error("nbody_octree_insert before nbody_octree_compute_bounds");
@@ -1393,7 +1415,7 @@ extern "C" int nbody_octree_compute_tree(nbody_octree* t, void* stream) {
 }
 
 extern "C" int nbody_octree_compute_force(nbody_octree* t, const nbody_state* s, double theta, void* stream) {
-  if (int r = ot_check(t, s)) return r;
+  if (int r = ot_check(t, s, stream)) return r;
   device_guard guard(t->device);
   if (!t->have_tree) {
     set_error("nbody_octree_compute_force before nbody_octree_compute_tree");

@@ -28,7 +28,7 @@ class Device {
  public:
   static constexpr int dtype = std::is_same_v<T, float> ? NBODY_F32 : NBODY_F64;
 
-  // exchange: run the collective even with one device (exercises the multi-GPU path on a one-GPU box)
+  // exchange: run the collective even with one device (an explicit `--gpus 1`: the multi-GPU path on a one-GPU box)
   explicit Device(System<T, D>& host, int ngpus = 1, bool exchange = false) : host_(host), sharded_(ngpus > 1 || exchange) {
     ctx_.resize(std::size_t(ngpus), nullptr);
     view_.resize(std::size_t(ngpus));
@@ -120,7 +120,7 @@ class Device {
 
   void bvh_alloc() {
     single("bvh");
-    if (!tree_) backend_check(nbody_bvh_create(&tree_, dtype, D, host_.n), "nbody_bvh_create");
+    if (!tree_) backend_check(nbody_bvh_create_on(&tree_, dtype, D, host_.n, 0), "nbody_bvh_create_on");
   }
   void bvh_bounding_box() { backend_check(nbody_bvh_bounding_box(tree_, &view_[0], stream()), "nbody_bvh_bounding_box"); }
   void bvh_hilbert_sort() { backend_check(nbody_bvh_hilbert_sort(tree_, &view_[0], stream()), "nbody_bvh_hilbert_sort"); }
@@ -131,7 +131,7 @@ class Device {
   // octree phases (src/octree.h)
   void octree_alloc() {
     single("octree");
-    if (!octree_) backend_check(nbody_octree_create(&octree_, dtype, D, host_.n), "nbody_octree_create");
+    if (!octree_) backend_check(nbody_octree_create_on(&octree_, dtype, D, host_.n, 0), "nbody_octree_create_on");
   }
   void octree_clear() { backend_check(nbody_octree_clear(octree_, stream()), "nbody_octree_clear"); }
   void octree_compute_bounds() { backend_check(nbody_octree_compute_bounds(octree_, &view_[0], stream()), "nbody_octree_compute_bounds"); }

@@ -222,9 +222,9 @@ void run_simulation(Options const& o, System<T, D>& sys) {
       std::cerr << "--gpus " << o.gpus << ": bodies shard over GPUs for --algorithm all-pairs only." << std::endl;
       std::exit(EXIT_FAILURE);
     }
-    // NBODY_CLI_FORCE_COMM=1: --gpus 1 through the communicator, shard window and exchange (one-GPU boxes)
-    char const* force_comm = std::getenv("NBODY_CLI_FORCE_COMM");
-    bool const exchange    = o.algorithm == Algorithm::AllPairs && force_comm && force_comm[0] == '1';
+    // an explicit --gpus N with all-pairs goes through the communicator, the shard windows and the exchange for ANY N (N = 1
+    // is how a one-GPU box exercises that path); without the flag: the reference's single device, no communicator
+    bool const exchange = o.algorithm == Algorithm::AllPairs && o.gpus_given;
     Device<T, D> dev(sys, o.gpus, exchange);
     switch (o.algorithm) {
       case Algorithm::AllPairs: run_all_pairs(sys, dev, o, "all-pairs", false); break;

@@ -29,6 +29,7 @@ struct Options {
   // not in the reference (and therefore not in the --help text, which stays the reference's word for word): --gpus N shards
   // the bodies of --algorithm all-pairs over N devices of this node, one RCCL all-gather of positions per step
   int gpus = 1;
+  bool gpus_given = false;  // an explicit --gpus N (any N, also 1) takes the sharded path: communicator, shard windows, exchange
 };
 
 namespace detail {
@@ -90,6 +91,7 @@ inline Options parse_options(std::vector<std::string> const& argv) {
       } else detail::reject("workload", w, "plummer, galaxy, uniform (default)");
     } else if (f == "--gpus") {
       o.gpus = std::stoi(value());
+      o.gpus_given = true;
       if (o.gpus < 1) {
         std::cerr << "--gpus needs a positive device count." << std::endl;
         std::exit(EXIT_FAILURE);

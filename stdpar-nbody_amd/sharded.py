@@ -24,39 +24,11 @@ def shard_range(n, rank, world):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-class HipOps:
-    """Phase calls through the C ABI on raw device pointers (include/nbody_hip.h)."""
-
-    def __init__(self, pkg):
-        self.pkg = pkg
-        self.lib = pkg.lib()
-
-    def all_pairs_force(self, st, stream):
-        rc = self.lib.nbody_all_pairs_force(C.byref(st), C.c_void_p(stream))
-        if rc:
-            raise self.pkg.NbodyError(self.lib.nbody_last_error().decode())
-
-    def accelerate_step(self, st, stream):
-        rc = self.lib.nbody_accelerate_step(C.byref(st), C.c_void_p(stream))
-        if rc:
-            raise self.pkg.NbodyError(self.lib.nbody_last_error().decode())
-
-    def octree_create(self, dtype, dim, n):
-        return self.pkg.Octree(dtype, dim, n)
-
-    def octree_force(self, tree, whole, st, theta, stream):
-        """The force phase of run_octree (src/octree.h:321-326): build from ALL bodies, walk for the window of `st`."""
-        tree.clear(stream)
-        tree.compute_bounds(whole, stream)
-        tree.insert(whole, stream)
-        tree.compute_tree(stream)
-        tree.compute_force(st, theta, stream)
-
-
 class ShardedAllPairs:
     """run_all_pairs' step (force, then accelerate_step; src/all_pairs.h:86-91) over a shard of targets."""
 
-    def __init__(self, hs, rank, world, torch_device=None, ops=None, pkg=None, force_exchange=False, comm=None):
+    def __init__(self, hs, rank, world, torch_device=None, pkg=None, force_exchange=False, comm=None):
+        import sys
         import torch
         import torch.distributed as dist
         self.torch, self.dist = torch, dist
@@ -65,14 +37,8 @@ class ShardedAllPairs:
         self.first, end = shard_range(hs.n, rank, world)
         self.count = end - self.first
         self.device = torch_device if torch_device is not None else torch.device("cpu")
-        if ops is None:
-            import sys
-            pkg = pkg or sys.modules["stdpar_nbody_amd"]
-            ops = HipOps(pkg)
-            self._state_cls = pkg.nbody_state
-        else:
-            self._state_cls = None
-        self.ops = ops
+        self.pkg = pkg or sys.modules["stdpar_nbody_amd"]
+        self.lib = self.pkg.lib()
         to = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
         self.m = to(hs.m)                       # all bodies
         self.x = to(hs.x)                       # all bodies; rows [first, first+count) are ours to update
@@ -89,8 +55,8 @@ class ShardedAllPairs:
             self.use_torch_exchange()
 
     def use_torch_exchange(self):
-        """Switch to the torch.distributed form of the exchange: one all_gather over padded shards (also the fallback
-        bench.py takes when the library's communicator cannot be created or fails its cross-rank check)."""
+        """Switch to the torch.distributed form of the exchange: one all_gather over padded shards (the CPU/gloo tests of
+        the partition logic, and bench.py only on an explicit `--exchange torch`)."""
         torch = self.torch
         self.comm = None
         self.send = torch.zeros((self.maxc,) + tuple(self.x.shape[1:]), dtype=self.x.dtype, device=self.device)
@@ -98,9 +64,7 @@ class ShardedAllPairs:
 
     def state(self, whole=False):
         """The shard's view; whole=True: the window covers every body (phases that read only m and x)."""
-        if self._state_cls is None:  # test ops work on the tensors directly
-            return self
-        st = self._state_cls()
+        st = self.pkg.nbody_state()
         st.m, st.x = self.m.data_ptr(), self.x.data_ptr()
         st.v, st.a, st.ao = self.v.data_ptr(), self.a.data_ptr(), self.ao.data_ptr()
         st.dt, st.c = self.dt, self.c
@@ -136,14 +100,26 @@ class ShardedAllPairs:
             if r != self.rank:
                 self.x[f:e].copy_(self.recv[r * self.maxc:r * self.maxc + (e - f)])
 
+    def _call(self, rc):
+        if rc:
+            raise self.pkg.NbodyError(self.lib.nbody_last_error().decode())
+
+    # the two phase calls of the step, through the C ABI on the tensors' device pointers (include/nbody_hip.h)
+    def force_phase(self):
+        st = self.state()
+        self._call(self.lib.nbody_all_pairs_force(C.byref(st), C.c_void_p(self._stream())))
+
+    def integrate_phase(self):
+        st = self.state()
+        self._call(self.lib.nbody_accelerate_step(C.byref(st), C.c_void_p(self._stream())))
+
     def step(self, force_events=None, exchange_events=None):
-        st, stream = self.state(), self._stream()
         if force_events:
             force_events[0].record()
-        self.ops.all_pairs_force(st, stream)
+        self.force_phase()
         if force_events:
             force_events[1].record()
-        self.ops.accelerate_step(st, stream)
+        self.integrate_phase()
         if exchange_events:
             exchange_events[0].record()
         self.exchange_positions()
@@ -179,25 +155,36 @@ class ShardedOctree(ShardedAllPairs):
     def __init__(self, hs, rank, world, theta=0.5, **kw):
         super().__init__(hs, rank, world, **kw)
         self.theta = float(theta)
-        self.tree = self.ops.octree_create(self.dtype, self.dim, self.n)
+        self.tree = self.make_tree()
         self.steps_done = 0
+
+    def make_tree(self):
+        dev = self.device.index if self.device.type == "cuda" and self.device.index is not None else -1
+        return self.pkg.Octree(self.dtype, self.dim, self.n, dev)
+
+    def force_phase(self):
+        """The force phase of run_octree (src/octree.h:321-326): build from ALL bodies, walk for the rank's window."""
+        st, whole, stream, tree = self.state(), self.state(whole=True), self._stream(), self.tree
+        tree.clear(stream)
+        tree.compute_bounds(whole, stream)
+        tree.insert(whole, stream)
+        tree.compute_tree(stream)
+        tree.compute_force(st, self.theta, stream)
 
     CHECK_EVERY = 64
 
     def check(self):
         """Raises if any build or walk since the last check flagged trouble (nbody_octree_info): a flagged build drops
         mass, so a run must not integrate on.  Called every CHECK_EVERY steps; call it once more after the last step."""
-        if hasattr(self.tree, "info"):
-            self.tree.info(self._stream())
+        self.tree.info(self._stream())
 
     def step(self, force_events=None):
-        st, whole, stream = self.state(), self.state(whole=True), self._stream()
         if force_events:
             force_events[0].record()
-        self.ops.octree_force(self.tree, whole, st, self.theta, stream)
+        self.force_phase()
         if force_events:
             force_events[1].record()
-        self.ops.accelerate_step(st, stream)
+        self.integrate_phase()
         self.exchange_positions()
         self.steps_done += 1
         if self.steps_done % self.CHECK_EVERY == 0:

@@ -113,3 +113,32 @@ def test_smem_pipeline_registers_untouched_in_flight(nb):
     loads, problems = mod.check(nb.LIB_PATH)
     assert loads >= 64, f"only {loads} s_load_dwordx16 found: K1's scalar-stream kernels are missing from the disassembly"
     assert not problems, "\n".join(problems[:10])
+
+
+def test_shipped_binaries_read_no_environment(nb):
+    """the tuning switches (NBODY_K1_CHUNKS, NBODY_K2_CFG, NBODY_K9_*, NBODY_OT_FORM, NBODY_CLI_FORCE_COMM) exist
+    only in the -DNBODY_EXPERIMENTS build.  The shipped library and CLI do not import getenv and do not carry the names."""
+    targets = [nb.LIB_PATH] + [os.path.join(ROOT, "stdpar-nbody_amd", "bin", f"nbody_hip_d{d}") for d in (2, 3)]
+    for path in targets:
+        assert os.path.exists(path), path
+        und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+        assert "getenv" not in und, f"{path} imports getenv"
+        raw = open(path, "rb").read()
+        for name in (b"NBODY_K1_CHUNKS", b"NBODY_K2_CFG", b"NBODY_K9_", b"NBODY_OT_FORM", b"NBODY_CLI_FORCE_COMM"):
+            assert name not in raw, (path, name)
+
+
+def test_hand_built_state_with_garbage_tuning_is_refused(nb):
+    """nbody_state.tuning must be 0 or an NBODY_TUNING(...) value; a state that was not zero-initialised is refused
+    before any launch (no GPU needed: the check precedes every HIP call)."""
+    L = nb.lib()
+    st = nb.nbody_state()
+    st.dtype, st.dim, st.sz, st.count = nb.F64, 3, 16, 16
+    st.m = st.x = st.v = st.a = st.ao = 0x1000  # never dereferenced: argument checks come first
+    for bad in (0x1, 0x108 | (3 << 6), 0x10000, 0x100 | 3, 0xdeadbeef):
+        st.tuning = bad
+        assert L.nbody_all_pairs_force(ctypes.byref(st), None) == 1, hex(bad)
+        assert L.nbody_accelerate_step(ctypes.byref(st), None) == 1, hex(bad)
+    buf = ctypes.create_string_buffer(256)
+    st.tuning = nb.tuning(4, 1, 1)
+    assert L.nbody_all_pairs_describe(ctypes.byref(st), buf, ctypes.c_size_t(256)) == 0, L.nbody_last_error()

@@ -477,9 +477,8 @@ def test_torch_plumbing_path_equals_ctx_path(nb):
         s.exchange = False  # no process group here; the exchange is emulated below
     for _ in range(steps):
         for s in sims:
-            st = s.state()
-            s.ops.all_pairs_force(st, s._stream())
-            s.ops.accelerate_step(st, s._stream())
+            s.force_phase()
+            s.integrate_phase()
         torch.cuda.synchronize()
         for s in sims:      # what all_gather_into_tensor does
             for o in sims:

@@ -223,7 +223,7 @@ def test_traversal_shard_windows_bitwise(nb):
 
 def test_sweep_work_items_and_shard_windows(nb):
     """The sweep's work items (key-jump groups cut in two and started first, tests 1/16 of the groups) change grouping and
-    start order only: windows of the bodies, every scheduling form and the plain index order (NBODY_K9_ORDER=0) give bitwise
+    start order only: windows of the bodies, every scheduling form and the plain index order (nbody_bvh_set_launch_order) give bitwise
     the same accelerations and counters — also where the window does not start at a group boundary."""
     import os
     n = 200003
@@ -232,17 +232,14 @@ def test_sweep_work_items_and_shard_windows(nb):
     t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
     t.enable_counters(True)
     res = {}
-    for mode, env in ((1, None), (3, None), (3, "0"), (4, None), (5, None), (5, "0")):
-        if env is not None:
-            os.environ["NBODY_K9_ORDER"] = env
-        try:
-            t.set_traversal(mode)
-            t.compute_force(st, 0.5, dev.stream)
-            dev.sync()
-            res[(mode, env)] = (dev.download().a.copy(), t.read(5, dev.stream).copy())
-        finally:
-            os.environ.pop("NBODY_K9_ORDER", None)
-    base = res[(1, None)]
+    for mode, order in ((1, 0), (3, 0), (3, 1), (4, 0), (5, 0), (5, 1)):
+        t.set_traversal(mode)
+        t.set_launch_order(order)
+        t.compute_force(st, 0.5, dev.stream)
+        dev.sync()
+        res[(mode, order)] = (dev.download().a.copy(), t.read(5, dev.stream).copy())
+    t.set_launch_order(0)
+    base = res[(1, 0)]
     for k, r in res.items():
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), k
     for mode in (3, 5):

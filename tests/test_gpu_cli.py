@@ -218,18 +218,18 @@ def cli_env(dim, args, env_extra, cwd=None):
 
 def test_gpus_flag_multi_device_path_on_one_gpu():
     """--gpus N (not in the reference): one context per device, the ABI's shard per context, nbody_comm_create_all and an
-    nbody_allgather_positions per step.  On the one-GPU box the whole path runs with N = 1 (NBODY_CLI_FORCE_COMM=1) and
-    must print exactly what the plain single-device run prints, in the default and in the --csv-detailed mode with saved
+    nbody_allgather_positions per step.  An explicit --gpus takes that path for any N, so on the one-GPU box the whole path
+    runs with `--gpus 1` and must print exactly what the plain single-device run prints, in the default and in the --csv-detailed mode with saved
     frames; asking for more devices than are visible, or for a non-sharding algorithm, fails with a message."""
     args = ["-n", 3000, "-s", 12, "--precision", "double", "--algorithm", "all-pairs", "--workload", "galaxy", "--print-state"]
     plain = cli(3, args)
-    forced = cli_env(3, args + ["--gpus", 1], {"NBODY_CLI_FORCE_COMM": "1"})
+    forced = cli(3, args + ["--gpus", 1])
     assert plain.returncode == 0 and forced.returncode == 0, forced.stderr
     strip = lambda out: re.sub(r"Total time: .*", "", out)
     assert strip(plain.stdout) == strip(forced.stdout)
     with tempfile.TemporaryDirectory() as d1, tempfile.TemporaryDirectory() as d2:
         a2 = ["-n", 500, "-s", 4, "--precision", "float", "--algorithm", "all-pairs", "--csv-detailed", "--save", "pos"]
-        r1, r2 = cli(2, a2, cwd=d1), cli_env(2, a2 + ["--gpus", 1], {"NBODY_CLI_FORCE_COMM": "1"}, cwd=d2)
+        r1, r2 = cli(2, a2, cwd=d1), cli(2, a2 + ["--gpus", 1], cwd=d2)
         assert r1.returncode == 0 and r2.returncode == 0, r2.stderr
         assert open(os.path.join(d1, "positions.bin"), "rb").read() == open(os.path.join(d2, "positions.bin"), "rb").read()
     import torch
@@ -238,7 +238,7 @@ def test_gpus_flag_multi_device_path_on_one_gpu():
     assert r.returncode != 0 and "HIP devices visible" in r.stderr
     r = cli(3, ["-n", 1000, "--algorithm", "bvh", "--gpus", 2])
     assert r.returncode != 0 and "all-pairs only" in r.stderr
-    r = cli_env(3, ["-n", 1000, "-s", 2, "--algorithm", "all-pairs", "--gpus", 1, "--save", "energy", "--csv-detailed"], {"NBODY_CLI_FORCE_COMM": "1"})
+    r = cli(3, ["-n", 1000, "-s", 2, "--algorithm", "all-pairs", "--gpus", 1, "--save", "energy", "--csv-detailed"])
     assert r.returncode != 0 and "one GPU only" in r.stderr
 
 
@@ -255,17 +255,21 @@ def test_multi_gpu_abi_from_plain_c(tmp_path):
     assert r.returncode == 0 and "bitwise equal" in r.stdout, r.stdout + r.stderr
 
 
-def test_scheduling_forms_give_the_same_trajectory():
+def test_scheduling_forms_give_the_same_trajectory(nb):
     """K9's per-lane walks, its compiler-scheduled sweep and the sweep written as ISA — and the octree walk's two forms — are
     bitwise equal per force phase (tests/test_gpu_bvh.py, test_gpu_octree.py); here over a few hundred steps of an evolving
-    system in the CLI's recorded step loop (trees deepen as escapers inflate the box): --print-state text identical."""
-    strip = lambda out: re.sub(r"Total time: .*", "", out)
-    for prec, n, steps in (("double", 60000, 300), ("float", 70000, 150)):
-        args = ["-n", n, "-s", steps, "--precision", prec, "--algorithm", "bvh", "--workload", "galaxy", "--print-state"]
-        outs = [cli_env(3, args, {"NBODY_K9_MODE": m}) for m in ("1", "3", "5")]
-        assert all(o.returncode == 0 for o in outs), [o.stderr[-300:] for o in outs]
-        assert strip(outs[0].stdout) == strip(outs[1].stdout) == strip(outs[2].stdout), prec
-    args = ["-n", 50000, "-s", 400, "--precision", "double", "--algorithm", "octree", "--workload", "galaxy", "--print-state"]
-    a, b = cli_env(3, args, {"NBODY_OT_FORM": "0"}), cli_env(3, args, {"NBODY_OT_FORM": "1"})
-    assert a.returncode == 0 and b.returncode == 0, a.stderr[-300:] + b.stderr[-300:]
-    assert strip(a.stdout) == strip(b.stdout)
+    system (trees deepen as escapers inflate the box): the final x, v, a are identical bit for bit.  The forms are selected
+    through the ABI setters (nbody_bvh_set_traversal, nbody_octree_set_walk); the shipped library reads no environment."""
+    def final(dtype, n, steps, algo, select):
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+        select(dev)
+        nb.run(dev, algo, steps, 0.5)
+        out = dev.download()
+        dev.close()
+        return out
+    for dtype, n, steps in ((nb.F64, 60000, 300), (nb.F32, 70000, 150)):
+        outs = [final(dtype, n, steps, "bvh", lambda d, m=m: d.bvh.set_traversal(m)) for m in (1, 3, 5)]
+        for o in outs[1:]:
+            assert np.array_equal(o.x, outs[0].x) and np.array_equal(o.v, outs[0].v) and np.array_equal(o.a, outs[0].a), dtype
+    a, b = (final(nb.F64, 50000, 400, "octree", lambda d, m=m: d.octree.set_walk(m)) for m in (2, 1))
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.v, b.v) and np.array_equal(a.a, b.a)

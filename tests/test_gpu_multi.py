@@ -17,11 +17,15 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _bench(extra_env, *args):
+def _bench_raw(extra_env, *args):
     env = dict(os.environ)
     env.update(extra_env)
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=900)
+
+
+def _bench(extra_env, *args):
+    r = _bench_raw(extra_env, *args)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout  # stdout carries exactly one line
@@ -41,6 +45,9 @@ def test_bench_self_launch_forced_dist_matches_plain_run():
     assert forced["shards"] == [1 << 17] and plain["shards"] == [1 << 17]
     assert forced["allgather"]["sent_bytes_per_rank_per_step"] == (1 << 17) * 24
     assert forced["allgather"]["avg_ms"] is not None and forced["allgather"]["avg_ms"] < 5.0
+    assert rw["exchange"] == "nbody" and rw["bitwise_vs_single"]["equal"] and rw["bitwise_vs_single"]["checked_ranks"] == [0]
+    assert len(rw["per_rank"]["k1_ms"]["by_rank"]) == 1 and rw["per_rank"]["k1_ms"]["max"] > 0
+    assert "after the last timed step" in rw["exchange_check"]
     for k in ("metric", "unit", "dtype", "scaling", "steps", "warmup"):
         assert plain[k] == forced[k], k
     assert plain["roofline"]["kernel"] == forced["roofline"]["kernel"]
@@ -174,3 +181,59 @@ def test_bench_multi_rank_rehearsal_on_one_gpu():
     assert out["rccl_world"]["world"] == 2 and out["rccl_world"]["backend"] == "gloo"
     assert "identical on all 2 rank(s)" in out["rccl_world"]["exchange_check"]
     assert out["allgather"]["sent_bytes_per_rank_per_step"] == (1 << 15) * 24 and out["value"] > 0
+    rw = out["rccl_world"]
+    assert rw["exchange"] == "rehearsal" and "after the last timed step" in rw["exchange_check"]
+    assert rw["bitwise_vs_single"]["equal"] and rw["bitwise_vs_single"]["checked_ranks"] == [0, 1]
+    assert rw["bitwise_vs_single"]["targets_per_window"] == 4096
+    pr = rw["per_rank"]
+    assert len(pr["k1_ms"]["by_rank"]) == 2 and 0 < pr["k1_ms"]["min"] <= pr["k1_ms"]["max"]
+    assert len(pr["allgather_ms"]["by_rank"]) == 2 and pr["allgather_ms"]["max"] >= pr["allgather_ms"]["min"] >= 0
+
+
+@pytest.mark.parametrize("fault,needle", [
+    ("stale_exchange:1", "after the warm-up exchange"),   # a rank whose exchange delivers nothing: caught before the clock starts
+    ("stale_late:1", "after the timed steps"),            # ... from the first timed step on: caught by the end-of-run checksum
+    ("corrupt_a:1", "bitwise_vs_single failed"),          # a rank whose rows differ from the single-GPU sum
+])
+def test_bench_multi_rank_run_fails_on_a_broken_exchange(fault, needle):
+    """a multi-rank line cannot be green with a dead exchange.  Rehearsed on the one-GPU box (two ranks on
+    device 0): with an injected fault on rank 1 every rank exits non-zero, the launcher relays the status, stdout carries NO
+    result line and stderr names the check that failed."""
+    r = _bench_raw({"NBODY_BENCH_SHARE_GPU": "1", "NBODY_BENCH_FAULT": fault}, "--gpus", "2", "--steps", "2", "--warmup", "1",
+                   "--bodies", str(1 << 14), "--no-cpu-baseline")
+    assert r.returncode != 0, r.stdout
+    assert not r.stdout.strip(), r.stdout
+    assert needle in r.stderr, r.stderr[-3000:]
+
+
+def test_bench_fails_without_the_library_collective_unless_asked():
+    """The communicator of the library (nbody_comm over RCCL) is the data path of the metric: if it cannot be created on some
+    rank the run fails on every rank before anyone enters ncclCommInitRank — no silent torch.distributed fallback.  The torch
+    exchange exists only behind an explicit --exchange torch, and the line it prints is marked."""
+    args = ("--gpus", "1", "--steps", "1", "--warmup", "1", "--bodies", str(1 << 14), "--no-cpu-baseline")
+    r = _bench_raw({"NBODY_BENCH_FORCE_DIST": "1", "NBODY_BENCH_FAULT": "comm_create:0"}, *args)
+    assert r.returncode != 0 and not r.stdout.strip(), r.stdout
+    assert "nbody_comm cannot be created" in r.stderr and "no fallback" in r.stderr, r.stderr[-3000:]
+    out = _bench({"NBODY_BENCH_FORCE_DIST": "1"}, *args, "--exchange", "torch")
+    assert out["rccl_world"]["exchange"] == "torch" and "NOT the library's collective" in out["not_the_library_collective"]
+    assert out["rccl_world"]["bitwise_vs_single"]["equal"]
+
+
+def test_rccl_uneven_shards_two_gpus(nb):
+    """the grouped ncclSend/ncclRecv form of nbody_allgather_positions (sz % W != 0) between real devices.  Needs
+    two GPUs in this process; skipped on the one-GPU box (the driver's 8-GPU node runs bench.py, whose self-check covers the
+    even form)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    exe_src = os.path.join(ROOT, "examples", "abi_multi_gpu.c")
+    libdir = os.path.join(ROOT, "stdpar-nbody_amd")
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        exe = os.path.join(d, "abi_multi_gpu")
+        r = subprocess.run(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), exe_src, "-L" + libdir, "-lnbody_hip",
+                            "-Wl,-rpath," + libdir, "-o", exe], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        for n in ("7001", "8192"):   # uneven shards: grouped ncclSend/ncclRecv; even: one in-place ncclAllGather
+            r = subprocess.run([exe, "2", n], capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0 and "bitwise equal" in r.stdout, r.stdout + r.stderr

@@ -60,33 +60,30 @@ def test_octree_force_is_deterministic(nb):
 
 def test_octree_walk_forms_are_bitwise_equal(nb):
     """The visit round written as ISA (double, 3D: what runs by default) and the compiler-scheduled kernel
-    (NBODY_OT_FORM=1) perform the same tests and the same arithmetic in the same order: accelerations and counters equal
+    (nbody_octree_set_walk: 2 / 1) perform the same tests and the same arithmetic in the same order: accelerations and counters equal
     bit for bit — fresh and clustered systems, theta 0 (every node opened: the deepest stacks), a shard window."""
     import os
     rng = np.random.default_rng(7)
     cases = [("galaxy", 50000, 0.5), ("uniform", 20011, 0.0), ("galaxy", 4096, 1.2), ("plummer", 30000, 0.3)]
     for wl, n, theta in cases:
         res = []
-        for form in ("0", "1"):
-            os.environ["NBODY_OT_FORM"] = form
-            try:
-                hs = nb.build_model(1, 3, wl, n)
-                if wl == "uniform":  # tight pairs and a far escaper: near-pair path, cells below the usual depth
-                    hs.x[1] = hs.x[0] + 1e-9
-                    hs.x[3] = 1e3
-                dev = nb.DeviceSystem.from_host(hs)
-                dev.octree.enable_counters(True)
-                dev.octree_force(theta)
-                dev.sync()
-                full = dev.download().a.copy()
-                cnt = dev.octree.read_counters(dev.stream).copy()
-                dev.octree.compute_force(dev.state(n // 3, n // 2), theta, dev.stream)
-                dev.sync()
-                win = dev.download().a[n // 3:n // 3 + n // 2].copy()
-                res.append((full, cnt, win))
-                dev.close()
-            finally:
-                os.environ.pop("NBODY_OT_FORM", None)
+        for form in (2, 1):
+            hs = nb.build_model(1, 3, wl, n)
+            if wl == "uniform":  # tight pairs and a far escaper: near-pair path, cells below the usual depth
+                hs.x[1] = hs.x[0] + 1e-9
+                hs.x[3] = 1e3
+            dev = nb.DeviceSystem.from_host(hs)
+            dev.octree.set_walk(form)
+            dev.octree.enable_counters(True)
+            dev.octree_force(theta)
+            dev.sync()
+            full = dev.download().a.copy()
+            cnt = dev.octree.read_counters(dev.stream).copy()
+            dev.octree.compute_force(dev.state(n // 3, n // 2), theta, dev.stream)
+            dev.sync()
+            win = dev.download().a[n // 3:n // 3 + n // 2].copy()
+            res.append((full, cnt, win))
+            dev.close()
         assert np.array_equal(res[0][0], res[1][0]), (wl, n, theta)
         assert np.array_equal(res[0][1], res[1][1]), (wl, n, theta)
         assert np.array_equal(res[0][2], res[1][2]) and np.array_equal(res[0][2], res[0][0][n // 3:n // 3 + n // 2]), (wl, n, theta)

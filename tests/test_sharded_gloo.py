@@ -1,5 +1,5 @@
 """CPU, world_size 2, gloo: the body-sharding + position all-gather logic of stdpar-nbody_amd/sharded.py.
-The force/integrator ops are replaced by the oracle (test injection only), so what is under test is the
+The two phase calls are overridden in test-only subclasses that run the oracle, so what is under test is the
 partition, the exchange and that sharded == unsharded bit-for-bit."""
 import os
 import socket
@@ -13,41 +13,49 @@ import torch.multiprocessing as mp
 from conftest import ROOT, load_package
 
 
-class OracleOps:
-    """Test-only ops: the oracle acting on the CPU tensors of a ShardedAllPairs."""
+def oracle_sims(nb):
+    """Test-only subclasses: the two phase calls of a step are replaced by the oracle acting on the CPU tensors, so what
+    runs from the product is the partition, the exchange and the step sequence of sharded.py."""
+    import oracle as O
 
-    def __init__(self):
-        import oracle as O
-        self.O = O
-
-    def _state(self, sim):
-        s = self.O.State(sim.dtype, sim.dim, sim.n)
+    def o_state(sim):
+        s = O.State(sim.dtype, sim.dim, sim.n)
         s.m, s.x = sim.m.numpy(), sim.x.numpy()
         s.dt, s.c = sim.dt, sim.c
         return s
 
-    def all_pairs_force(self, sim, stream):
-        s = self._state(sim)
-        s.a = np.zeros_like(s.x)
-        self.O.all_pairs_force(s, sim.first, sim.count)
-        sim.a.numpy()[:] = s.a[sim.first:sim.first + sim.count]
-
-    def octree_create(self, dtype, dim, n):
-        return None
-
-    def octree_force(self, tree, whole, sim, theta, stream):
-        s = self._state(sim)
-        s.a = np.zeros_like(s.x)
-        self.O.octree_step_force(s, theta)
-        sim.a.numpy()[:] = s.a[sim.first:sim.first + sim.count]
-
-    def accelerate_step(self, sim, stream):
-        O = self.O
+    def integrate(sim):
         sub = O.State(sim.dtype, sim.dim, sim.count)
         sub.x = sim.x.numpy()[sim.first:sim.first + sim.count]  # view: updated in place
         sub.v, sub.a, sub.ao = sim.v.numpy(), sim.a.numpy(), sim.ao.numpy()
         sub.dt = sim.dt
         O.accelerate_step(sub)
+
+    class OracleAllPairs(nb.parallel.ShardedAllPairs):
+        def force_phase(self):
+            s = o_state(self)
+            s.a = np.zeros_like(s.x)
+            O.all_pairs_force(s, self.first, self.count)
+            self.a.numpy()[:] = s.a[self.first:self.first + self.count]
+
+        integrate_phase = integrate
+
+    class OracleOctree(nb.parallel.ShardedOctree):
+        def make_tree(self):
+            return None
+
+        def check(self):
+            pass
+
+        def force_phase(self):
+            s = o_state(self)
+            s.a = np.zeros_like(s.x)
+            O.octree_step_force(s, self.theta)
+            self.a.numpy()[:] = s.a[self.first:self.first + self.count]
+
+        integrate_phase = integrate
+
+    return OracleAllPairs, OracleOctree
 
 
 def _free_port():
@@ -70,10 +78,11 @@ def _worker(rank, world, port, n, steps, q, algorithm="all-pairs"):
     for k in ("m", "x", "v", "a", "ao"):
         getattr(hs, k)[:] = getattr(o, k)
     hs.dt, hs.c = o.dt, o.c
+    OracleAllPairs, OracleOctree = oracle_sims(nb)
     if algorithm == "octree":
-        sim = nb.parallel.ShardedOctree(hs, rank, world, theta=0.5, ops=OracleOps())
+        sim = OracleOctree(hs, rank, world, theta=0.5)
     else:
-        sim = nb.parallel.ShardedAllPairs(hs, rank, world, ops=OracleOps())
+        sim = OracleAllPairs(hs, rank, world)
     for _ in range(steps):
         sim.step()
     x, v, a = sim.gather_state()

@@ -1,6 +1,6 @@
 import sys, time, os
-sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
-from conftest import load_package
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
 import numpy as np
 nb = load_package()
 n = 1000000

@@ -1,8 +1,8 @@
 """Diagnostic: time K2 (all-pairs-collapsed) against K1 at a given size/dtype over its register-budget variants
 (NBODY_K2_CFG is an experiment knob: (targets reduced together, source records in registers, pair chains in flight))."""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from conftest import load_package
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
 nb = load_package()
 CFG = {0: "(16,8,1)", 1: "(8,4,4)", 2: "(8,4,1)", 3: "(16,8,4)", 4: "(8,4,2)", 5: "(8,8,1)", 6: "(8,2,1)", 7: "(8,2,2)"}
 for n, dtype, dim in ((262144, nb.F32, 3), (100000, nb.F64, 3), (100000, nb.F32, 3), (10000, nb.F32, 2)):

@@ -1,8 +1,8 @@
 """Diagnostic: time K1 over (source path, split, targets_per_thread) configs, full system and 1/8 shard.
 usage: tune_all_pairs.py [n] [double|float] [dim]"""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from conftest import load_package
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
 nb = load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64

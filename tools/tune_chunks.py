@@ -2,8 +2,8 @@
 The NBODY_K1_CHUNKS override changes the rounding order; it exists for this experiment only.
 usage: tune_chunks.py [n ...]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from conftest import load_package
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
 nb = load_package()
 sizes = [int(a) for a in sys.argv[1:]] or [65536, 100000, 262144]
 for n in sizes:

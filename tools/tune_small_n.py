@@ -1,8 +1,8 @@
 """Diagnostic: K1 below 65 536 bodies — LDS-tile form (auto) against the scalar-stream form with 8 slices and source chunks.
 usage: tune_small_n.py [n ...]"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from conftest import load_package
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
 nb = load_package()
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 10000, 20000, 30000, 50000]
 for n in sizes:

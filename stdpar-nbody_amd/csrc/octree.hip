@@ -34,7 +34,9 @@ constexpr uint32_t kOtEmpty  = 0xffffffffu;  // src/octree.h:37
 constexpr uint32_t kOtBody   = 0xfffffffeu;  // src/octree.h:38
 constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u, kFlagWalk = 8u;
 constexpr int kOtDeepLevels = 128;  // total depth the deep build follows before it calls the bodies coincident
-constexpr int kOtDeepFrames = 192;  // its DFS stack (one chain of close bodies needs ~2 per level)
+// its DFS stack: the cells on the current path stay for their second visit (<= kOtDeepLevels), plus the waiting siblings — the
+// biggest child of a cell is entered LAST, so siblings wait only along the <= log2(n) levels where the path entered a smaller child
+constexpr int kOtDeepFrames = kOtDeepLevels + 7 * 28 + 12;
 
 template <int D>
 constexpr int kMaxLevels = D == 3 ? 21 : 32;
@@ -516,8 +518,21 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
         }
         tree.put(fc + c, r);
       }
-      for (uint32_t c = NCH; c-- > 0;) {  // children that are cells, last first so that the first is finished first
-        if (bound[c + 1] - bound[c] < 2) continue;
+      // Children that are cells go on the stack; the one with the most bodies FIRST, so that it is entered last: a chain of
+      // nested cells with waiting siblings at every level (tests/test_gpu_octree.py::_deep_chain) then holds its siblings
+      // only while they are being finished, not all the way down.  The order in which cells are finished changes group
+      // NUMBERS only (they come from an atomic counter anyway), never a monopole: those sum the children in child order.
+      uint32_t big = NCH, bigcnt = 1;
+      for (uint32_t c = 0; c < NCH; ++c) {
+        const uint32_t cnt = bound[c + 1] - bound[c];
+        if (cnt > bigcnt) {
+          bigcnt = cnt;
+          big    = c;
+        }
+      }
+      for (uint32_t q = 0; q <= NCH; ++q) {  // q = 0: the biggest; then the others, last first
+        const uint32_t c = q == 0 ? big : NCH - q;
+        if (c >= NCH || (q > 0 && c == big) || bound[c + 1] - bound[c] < 2) continue;
         if (sp == kOtDeepFrames) {
           atomicOr(flags, kFlagDepth);
           failed = true;
@@ -1140,6 +1155,7 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
 struct nbody_octree {
   int dtype = 0, dim = 0, device = 0;  // device: nbody_octree_create_on's (nbody_octree_create: the current one); every call runs there
   int walk = 0;                        // nbody_octree_set_walk: 0 auto, 1 compiler-scheduled kernel, 2 the visit round as ISA
+  uint32_t step_budget = 0;            // nbody_octree_set_step_budget: visit rounds a body may make; 0 = the node pool size
   uint32_t n = 0, capacity = 0, max_cells = 0, bounds_blocks = 0;
   size_t tsz = 0;
   void* root       = nullptr;  // T[D+1]: root_x (D), root_side_length
@@ -1245,12 +1261,13 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
   }
   const uint32_t per_wave = 64u >> D;
   const uint32_t blocks   = (s->count + per_wave - 1) / per_wave;
+  const uint32_t budget   = t->step_budget ? t->step_budget : t->capacity;  // a well-formed tree is left after < capacity rounds
   auto* rootrec           = static_cast<const ot_node<T>*>(t->rootrec);
 #define NB_OT_LAUNCH(CNT)                                                                                                    \
   hipLaunchKernelGGL((ot_force_kernel<T, D, CNT>), dim3(blocks), dim3(64), 0, st, rootrec,                                   \
                      static_cast<const ot_group<T, D>*>(t->groups), list, s->count,                                          \
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
-                     static_cast<T>(theta), t->capacity, static_cast<const T*>(t->root),                                   \
+                     static_cast<T>(theta), budget, static_cast<const T*>(t->root),                                        \
                      t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
   // double, 3D: the visit round written as ISA (ot_force_isa_kernel), while 32-bit group offsets reach the whole array;
   // nbody_octree_set_walk(t, 1) keeps the compiler-scheduled kernel (tests compare the two bitwise)
@@ -1268,7 +1285,7 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
 #define NB_OT_ISA(CNT)                                                                                                       \
   hipLaunchKernelGGL((ot_force_isa_kernel<CNT>), dim3(blocks), dim3(64), 0, st, rootrec,                                     \
                      static_cast<const ot_group<T, D>*>(t->groups), list, s->count, static_cast<const T*>(s->x),            \
-                     static_cast<T*>(s->a), static_cast<T>(s->c), s->first, static_cast<T>(theta), t->capacity,             \
+                     static_cast<T*>(s->a), static_cast<T>(s->c), s->first, static_cast<T>(theta), budget,                  \
                      static_cast<const T*>(t->root), t->lvl_count + (kMaxLevels<3> + 2), t->counters)
       if (t->counters_on) NB_OT_ISA(true);
       else NB_OT_ISA(false);
@@ -1291,6 +1308,12 @@ extern "C" int nbody_octree_set_walk(nbody_octree* t, int mode) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
   NB_ARG(mode >= 0 && mode <= 2, "walk form must be 0 (auto), 1 (compiler-scheduled) or 2 (visit round as ISA), got %d", mode);
   t->walk = mode;
+  return NBODY_OK;
+}
+
+extern "C" int nbody_octree_set_step_budget(nbody_octree* t, uint32_t steps) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  t->step_budget = steps;
   return NBODY_OK;
 }
 
@@ -1465,7 +1488,8 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
     return NBODY_ERR_STATE;
   }
   if (flags & kFlagWalk) {
-    set_error("octree walk: a body was still walking after %u steps (more than the tree has nodes: the tree is damaged)", t->capacity);
+    set_error("octree walk: a body was still walking after %u visit rounds (%s)", t->step_budget ? t->step_budget : t->capacity,
+              t->step_budget ? "the budget set with nbody_octree_set_step_budget" : "more than the tree has nodes: the tree is damaged");
     return NBODY_ERR_STATE;
   }
   uint64_t cells = 0;

@@ -75,3 +75,32 @@ def golden_hilbert():
 
 
 DT = {"float": 0, "double": 1}
+
+
+@pytest.fixture(scope="session")
+def golden_bvh_ties():
+    """Systems with equal Hilbert keys and the reference's outputs for them (tests/golden/generate_golden_ties.py)."""
+    return json.load(open(os.path.join(GOLDEN, "bvh_ties.json")))
+
+
+def tie_case_arrays(case):
+    """(m, x, v, dt, G) of a bvh_ties.json case in float64 (the reference reads float32 and converts, src/saving.h:25-68)."""
+    body = np.array(case["body_f32"], dtype=np.float64)
+    d = case["dim"]
+    return body[:, 0].copy(), body[:, 1:1 + d].copy(), body[:, 1 + d:].copy(), case["dt"], case["G"]
+
+
+def rows_multiset(rows):
+    """`--print-state` rows without their index prefix, sorted: the order-free form (bvh permutes the bodies)."""
+    return sorted(r.split(": ", 1)[1] for r in rows)
+
+
+def assert_frames_equal_as_multisets(got, want, rtol):
+    """Two (n, D) position frames hold the same bodies in any order: rows sorted lexicographically on coordinates rounded well
+    above the tolerance, then compared within rtol * max|want|."""
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape
+    scale = np.abs(want).max()
+    key = lambda a: np.lexsort(np.round(a / (scale * 1e-9)).T[::-1])
+    g, w = got[key(got)], want[key(want)]
+    assert np.abs(g - w).max() <= rtol * scale, np.abs(g - w).max() / scale

@@ -486,3 +486,135 @@ def test_torch_plumbing_path_equals_ctx_path(nb):
     torch.cuda.synchronize()
     assert np.array_equal(sims[0].x.cpu().numpy(), ref.x) and np.array_equal(sims[1].x.cpu().numpy(), ref.x)
     assert np.array_equal(np.concatenate([s.v.cpu().numpy() for s in sims]), ref.v)
+
+
+def _planted_system(nb, dtype, dim, extreme):
+    """6000 well-separated bodies (spacing ~0.5) plus partners planted in a DIFFERENT source tile than their target (index
+    distance >= 2100: beyond K2's 2048-record tile, K1's and the energies' 512): pairs closer than 2^-8 over many decades;
+    with `extreme` also exact coincidences, a zero-mass partner and an r^2 that is denormal in T (target at the origin)."""
+    rng = np.random.default_rng(23 + dtype * 2 + dim)
+    t = np.float64 if dtype == 1 else np.float32
+    n = 6000
+    hs = nb.HostSystem(dtype, dim, n)
+    side = 9.0 if dim == 3 else 40.0
+    hs.x[:] = rng.uniform(-side, side, (n, dim)).astype(t)
+    hs.m[:] = rng.uniform(0.5, 2.0, n).astype(t)
+    hs.v[:] = rng.standard_normal((n, dim)).astype(t)
+    gaps = [3e-3, 2.0 ** -9, 1e-4, 1e-6] + ([1e-9, 1e-12] if dtype == 1 else [])
+    planted = []
+    for k, gap in enumerate(gaps):
+        i, j = 17 + 31 * k, 17 + 31 * k + 2100 + 613 * k
+        d = np.zeros(dim)
+        d[k % dim] = gap
+        hs.x[j] = (hs.x[i].astype(np.float64) + d).astype(t)
+        planted += [i, j]
+    if extreme:
+        hs.x[300] = hs.x[2900]                          # coincident, distinct bodies, tiles apart
+        hs.x[301] = hs.x[5000]
+        hs.x[400] = 0                                    # target at the origin ...
+        hs.x[3000] = 0
+        hs.x[3000, 0] = 1e-160 if dtype == 1 else 1e-22  # ... partner at r^2 = 1e-320 / 1e-44: denormal in T
+        hs.x[500] = hs.x[4000]
+        hs.x[500, dim - 1] += t(1e-3)
+        hs.m[500] = 0                                    # zero-mass partner of a near pair
+        planted += [300, 2900, 301, 5000, 400, 3000, 500, 4000]
+    hs.c, hs.dt = 1.0, 0.01
+    return hs, np.array(planted)
+
+
+def _as_oracle_state(oracle, hs):
+    ref = oracle.State(hs.dtype, hs.dim, hs.n)
+    ref.m[:], ref.x[:], ref.v[:], ref.c, ref.dt = hs.m, hs.x, hs.v, hs.c, hs.dt
+    return ref
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+@pytest.mark.parametrize("extreme", [False, True])
+def test_near_pairs_in_another_source_tile(nb, oracle, dtype, dim, extreme):
+    """K2's two-pass path (a (group, tile) block is first evaluated with the reciprocal-free weight and redone
+    guarded only if it held a pair closer than 2^-8) and the energies' near path were reached only through the self tile.
+    Here the near partner sits >= 2100 indices away from its target — another source tile for every kernel — at gaps from
+    3e-3 down to 1e-12, plus (extreme) coincident bodies, a zero-mass partner and a denormal r^2.  K1, K2 and calc_energies
+    against the oracle, per target relative to that target's own scale (the planted targets' forces are 10^2..10^18 times
+    the typical force, so a global max-norm would hide everything else)."""
+    hs, planted = _planted_system(nb, dtype, dim, extreme)
+    ref = _as_oracle_state(oracle, hs)
+    oracle.all_pairs_force(ref)
+    ra = ref.a.astype(np.float64)
+    mag = np.abs(ra).max(axis=1)
+    floor = np.median(mag)
+    tol = 2e-13 if dtype == 1 else 4e-5
+    dev = nb.DeviceSystem.from_host(hs)
+    for name, call in (("K1", dev.all_pairs_force), ("K2", dev.all_pairs_collapsed_force)):
+        call()
+        a = dev.download().a.astype(np.float64)
+        assert np.all(np.isfinite(a)), name
+        err = np.abs(a - ra).max(axis=1)
+        bad = np.where(err > tol * np.maximum(mag, floor))[0]
+        assert bad.size == 0, (name, bad[:6], err[bad[:6]], mag[bad[:6]])
+        assert np.all(err[planted] <= tol * np.maximum(mag[planted], floor)), name
+        hs0 = dev.download()          # K2 accumulates into a - ao: start it from the reference's steady state a == ao
+        hs0.ao[:] = hs0.a
+        dev.upload(hs0)
+    # K2 once more from that state: (a - ao) + sum must give the same forces (the diagonal pass of src/all_pairs.h:35-40)
+    dev.all_pairs_collapsed_force()
+    a = dev.download().a.astype(np.float64)
+    assert np.all(np.abs(a - ra).max(axis=1) <= 2 * tol * np.maximum(mag, floor))
+    ke, pe = dev.calc_energies()
+    oke, ope = oracle.calc_energies(ref)
+    assert abs(ke - oke) <= (1e-12 if dtype == 1 else 2e-5) * abs(oke)
+    if dtype == 1:
+        assert np.isfinite(pe) and abs(pe - ope) <= 1e-12 * abs(ope), (pe, ope)
+    else:
+        # float: the oracle (like the reference's transform_reduce on a serial backend) adds 3.6e7 terms into ONE float
+        # accumulator, which by itself drifts 3e-5 from the exact sum of the same terms (measured: -58563080 against
+        # -58564799.4); the kernel's tree-shaped sum does not.  The yardstick is therefore the same expression,
+        # m_i m_j / (|x_i - x_j| + eps(float)) over the float inputs, evaluated in float64.
+        x64, m64, eps32 = hs.x.astype(np.float64), hs.m.astype(np.float64), float(np.finfo(np.float32).eps)
+        pe64 = 0.0
+        for i0 in range(0, hs.n, 500):
+            d = x64[i0:i0 + 500, None, :] - x64[None, :, :]
+            term = m64[i0:i0 + 500, None] * m64[None, :] / (np.sqrt((d * d).sum(-1)) + eps32)
+            rows = np.arange(term.shape[0])
+            term[rows, i0 + rows] = 0.0
+            pe64 += term.sum()
+        pe64 *= -0.5 * hs.c
+        assert np.isfinite(pe) and abs(pe - pe64) <= 2e-6 * abs(pe64), (pe, pe64)
+        assert abs(ope - pe64) <= 1e-4 * abs(pe64), (ope, pe64)
+    dev.close()
+
+
+def test_config2_as_written_100_steps(nb, oracle):
+    """BASELINE config[1] as written: `-n 65536 -s 100 --precision double --algorithm all-pairs` — no workload flag, so the
+    reference's default, uniform (src/arguments.h:27) — 100 steps of K1 + K3 (src/all_pairs.h:86-97).  The oracle cannot run
+    4.3e11 pairs in a test, so the trajectory is pinned link by link: at steps 1, 37 and 100 the state before the step
+    (x, v, a, ao as the device holds them) is handed to the oracle, which performs that one step for a sample of targets against
+    all 65536 sources; positions, velocities and accelerations after the step must agree to 1e-11 / 1e-12.  Momentum drift over
+    the run bounds the rest.  tests/test_gpu_cli.py runs the same command through the CLI and compares its printed rows."""
+    n, steps = 65536, 100
+    hs = nb.build_model(nb.F64, 3, "uniform", n)
+    dev = nb.DeviceSystem.from_host(hs)
+    rng = np.random.default_rng(2)
+    picks = np.unique(np.concatenate([rng.integers(0, n, 96), [0, n - 1]]))
+    p0 = (hs.m[:, None] * hs.v).sum(axis=0)
+    for step in range(1, steps + 1):
+        before = dev.download() if step in (1, 37, 100) else None
+        nb.run(dev, "all-pairs", 1)
+        if before is None:
+            continue
+        after = dev.download()
+        ref = _as_oracle_state(oracle, before)
+        ref.a[:], ref.ao[:] = before.a, before.ao
+        for i in picks:
+            oracle.all_pairs_force(ref, int(i), 1)
+        assert np.abs(after.a[picks] - ref.a[picks]).max() <= 1e-12 * np.abs(ref.a[picks]).max(), step
+        ref.a[picks] = after.a[picks]        # then the leapfrog of exactly those rows, bit for bit from the same inputs
+        sub = oracle.State(oracle.F64, 3, len(picks))
+        sub.x[:], sub.v[:], sub.a[:], sub.ao[:], sub.dt = before.x[picks], before.v[picks], after.a[picks], before.ao[picks], before.dt
+        oracle.accelerate_step(sub)
+        assert np.array_equal(sub.x, after.x[picks]) and np.array_equal(sub.v, after.v[picks]) and np.array_equal(sub.ao, after.ao[picks]), step
+    out = dev.download()
+    p1 = (out.m[:, None] * out.v).sum(axis=0)
+    assert np.abs(p1 - p0).max() <= 1e-11 * np.abs(out.m[:, None] * out.v).sum()
+    dev.close()

@@ -280,3 +280,34 @@ def test_traversal_terminates_on_nan_and_inf_positions():
     """ % os.path.join(root, "tests"))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "terminated" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_key_ties_match_the_reference_as_multisets(nb, oracle, golden_bvh_ties):
+    """VERDICT r2, missing #5: two bodies in one Hilbert cell.  The reference's sort is unstable (src/bvh.h:55-94), the
+    product's radix sort is stable, so only the multiset of final rows is specified: after 12 steps at theta = 0 the product's
+    `--print-state` rows equal the reference's (tests/golden/bvh_ties.json, generated from oracle/_ref) as multisets, for every
+    scheduling form of K9, and the last full-precision frame of a 4-step run agrees to 1e-11 as a multiset."""
+    from conftest import assert_frames_equal_as_multisets, rows_multiset, tie_case_arrays
+    for name, case in golden_bvh_ties.items():
+        def fresh():
+            hs = nb.HostSystem(nb.F64, case["dim"], case["n"])
+            hs.m[:], hs.x[:], hs.v[:], hs.dt, hs.c = tie_case_arrays(case)
+            return nb.DeviceSystem.from_host(hs)
+        dev = fresh()
+        st, t = dev.state(), dev.bvh
+        t.bounding_box(st, dev.stream)
+        t.hilbert_sort(st, dev.stream)
+        dev.sync()
+        keys = t.read(0, dev.stream)
+        assert len(np.unique(keys)) <= case["n"] - 3, name       # the ties are real on the device too
+        dev.close()
+        for mode in (1, 3, 5):
+            dev = fresh()
+            dev.bvh.set_traversal(mode)
+            nb.run(dev, "bvh", 12, 0.0)
+            assert rows_multiset(oracle.format_state_rows(dev.download())) == rows_multiset(case["final_rows_bvh"]), (name, mode)
+            dev.close()
+        dev = fresh()
+        nb.run(dev, "bvh", 4, 0.0)
+        assert_frames_equal_as_multisets(dev.download().x, case["bvh_last_frame"], 1e-11)
+        dev.close()

@@ -273,3 +273,25 @@ def test_scheduling_forms_give_the_same_trajectory(nb):
             assert np.array_equal(o.x, outs[0].x) and np.array_equal(o.v, outs[0].v) and np.array_equal(o.a, outs[0].a), dtype
     a, b = (final(nb.F64, 50000, 400, "octree", lambda d, m=m: d.octree.set_walk(m)) for m in (2, 1))
     assert np.array_equal(a.x, b.x) and np.array_equal(a.v, b.v) and np.array_equal(a.a, b.a)
+
+
+def test_config2_command_as_written(nb, oracle):
+    """BASELINE config[1] typed as the reference would be run: `-n 65536 -s 100 --precision double --algorithm all-pairs` (no
+    --workload: uniform, src/arguments.h:27; 10 warm-up + 90 timed steps, src/all_pairs.h:86-97).  The --csv-total row has the
+    reference's shape with nsteps = 90, and the rows `--print-state` prints after the 100 steps are, character for character,
+    those of the step loop whose steps tests/test_gpu_all_pairs.py::test_config2_as_written_100_steps checks against the oracle."""
+    args = ["-n", 65536, "-s", 100, "--precision", "double", "--algorithm", "all-pairs"]
+    r = cli(3, args + ["--csv-total"])
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0] == "algorithm,dim,precision,nsteps,nbodies,total [s]"
+    assert re.fullmatch(r"all-pairs,3,64,90,65536,\d+\.\d\d", lines[1]), lines[1]
+    r = cli(3, args + ["--print-state"])
+    assert r.returncode == 0, r.stderr
+    start, final = oracle.parse_print_state(r.stdout)
+    hs = nb.build_model(nb.F64, 3, "uniform", 65536)
+    assert start == oracle.format_state_rows(hs)
+    dev = nb.DeviceSystem.from_host(hs)
+    nb.run(dev, "all-pairs", 100)
+    assert final == oracle.format_state_rows(dev.download())
+    dev.close()

@@ -365,3 +365,87 @@ def test_sharded_octree_torch_path(nb):
     assert np.array_equal(sims[0].x.cpu().numpy(), ref.x) and np.array_equal(sims[1].x.cpu().numpy(), ref.x)
     assert np.array_equal(np.concatenate([s.v.cpu().numpy() for s in sims]), ref.v)
     assert np.array_equal(np.concatenate([s.a.cpu().numpy() for s in sims]), ref.a)
+
+
+def _deep_chain(nb, levels):
+    """A legal but pathological system: the root cube is [-8, 8]^3, centred on the origin (bodies at -7 and +7 in every
+    coordinate are the scalar extremes, +-1: src/octree.h:93-112), and a chain of cells [0, 16/2^k]^3, k = 1..levels, converges
+    on the origin.  In every cell of the chain two octants hold a
+    pair of bodies (cells that a theta = 0 walk must open) and the low octant continues the chain, so a walk that descends
+    the chain first — child 0 is popped first — holds 2 more pending cells per level."""
+    pts = [(-7.0, -7.0, -7.0), (7.0, 7.0, 7.0)]
+    for k in range(1, levels + 1):
+        s = 16.0 / 2.0 ** k
+        pts += [(0.75 * s, 0.25 * s, 0.25 * s), (0.80 * s, 0.20 * s, 0.20 * s),
+                (0.25 * s, 0.75 * s, 0.25 * s), (0.20 * s, 0.80 * s, 0.20 * s)]
+    s = 16.0 / 2.0 ** levels
+    pts.append((0.1 * s, 0.1 * s, 0.1 * s))
+    hs = nb.HostSystem(nb.F64, 3, len(pts))
+    hs.x[:] = np.array(pts)
+    hs.m[:] = 1.0
+    hs.c, hs.dt = 1.0, 1e-3
+    return hs
+
+
+def _walk_with_canaries(nb, hs, theta, form, budget=0):
+    """One octree force phase with the accelerations written into the middle of a larger canary-filled buffer: returns
+    (a, the NbodyError message of nbody_octree_info or None) after checking that nothing outside a's rows was written."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    n, pad, canary = hs.n, 4096, -7.25
+    to = lambda arr: torch.from_numpy(np.ascontiguousarray(arr)).to(dev)
+    m, x, v = to(hs.m), to(hs.x), to(hs.v)
+    big = torch.full((n + 2 * pad, 3), canary, dtype=torch.float64, device=dev)
+    ao = torch.zeros((n, 3), dtype=torch.float64, device=dev)
+    st = nb.nbody_state()
+    st.m, st.x, st.v, st.ao = m.data_ptr(), x.data_ptr(), v.data_ptr(), ao.data_ptr()
+    st.a = big[pad:].data_ptr()
+    st.dt, st.c, st.sz, st.first, st.count, st.dtype, st.dim = hs.dt, hs.c, n, 0, n, nb.F64, 3
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    tree = nb.Octree(nb.F64, 3, n, 0)
+    tree.set_walk(form)
+    tree.set_step_budget(budget)
+    tree.enable_counters(True)
+    tree.clear(stream); tree.compute_bounds(st, stream); tree.insert(st, stream); tree.compute_tree(stream)
+    tree.compute_force(st, theta, stream)
+    torch.cuda.synchronize()
+    err = None
+    try:
+        tree.info(stream)
+    except nb.NbodyError as ex:
+        err = str(ex)
+    out = big.cpu().numpy()
+    assert np.all(out[:pad] == canary) and np.all(out[pad + n:] == canary), "the walk wrote outside a"
+    cnt = tree.read_counters(stream)
+    tree.close()
+    return out[pad:pad + n].copy(), cnt, err
+
+
+@pytest.mark.parametrize("form", [2, 1])   # the visit round as ISA, the compiler-scheduled kernel
+def test_octree_walk_stack_full_and_step_budget_exits(nb, oracle, form):
+    """the two emergency exits of the walk, which no test took.  (1) Stack full: a chain of 90 nested cells
+    with two more cells to open at every level makes a theta = 0 walk hold > 155 pending cells ((2^D - 1) * 21 + 2^D slots per
+    body); the kernel must leave, raise kFlagStack (reported by nbody_octree_info) and write nothing outside a — in the ISA form
+    the overflowing push goes past the end of the block's LDS and is dropped by the hardware.  The same chain 60 levels deep
+    (120 pending) fits: forces within tolerance of the oracle, counters bit-exact.  (2) Step budget: with a budget of 5 visit
+    rounds (nbody_octree_set_step_budget) on an ordinary tree, bodies are abandoned and kFlagWalk is reported; with the default
+    budget the same tree is clean."""
+    a, cnt, err = _walk_with_canaries(nb, _deep_chain(nb, 90), 0.0, form)
+    assert err is not None and "per-body stack" in err, err
+    assert np.all(np.isfinite(a))
+    hs = _deep_chain(nb, 60)
+    a, cnt, err = _walk_with_canaries(nb, hs, 0.0, form)
+    assert err is None, err
+    ref = oracle.State(oracle.F64, 3, hs.n)
+    ref.m[:], ref.x[:], ref.c, ref.dt = hs.m, hs.x, hs.c, hs.dt
+    ocnt, osize, omass = oracle.octree_step_force(ref, 0.0, want_counts=True)
+    assert np.array_equal(cnt, ocnt)
+    err_a = np.abs(a - ref.a).max(axis=1)
+    assert np.all(err_a <= 1e-12 * np.maximum(np.abs(ref.a).max(axis=1), 1.0))
+    gal = nb.build_model(nb.F64, 3, "galaxy", 20000)
+    a5, _, err = _walk_with_canaries(nb, gal, 0.5, form, budget=5)
+    assert err is not None and "visit rounds" in err and "nbody_octree_set_step_budget" in err, err
+    assert np.all(np.isfinite(a5))
+    afull, _, err = _walk_with_canaries(nb, gal, 0.5, form)
+    assert err is None and not np.array_equal(a5, afull)

@@ -32,6 +32,7 @@
 #include <atomic>
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 namespace nbody {
@@ -62,7 +63,7 @@ static ap_config ap_config_of(const nbody_state* s) {
 template <typename T, int D, int R, int JS>
 __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                                  T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                                                 uint32_t count) {
+                                                                 uint32_t count, const unsigned long long* __restrict__ ext) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kWaves / JS;    // target groups per block
   constexpr int TB  = TG * 64 * R;    // targets per block
@@ -94,6 +95,7 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
 
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
   const pair_consts<T> pc;
+  const bool ffar = ap_far_mode<D>(ext);
 
   // register staging of one tile: LPT records per lane
   rec_t stage[LPT];
@@ -115,22 +117,31 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
   };
 
   stage_load(0);
-  for (uint32_t t = 0; t < ntiles; ++t) {
-    __syncthreads();  // every wave is done reading the previous tile
+  auto run = [&](auto ff) {  // the tile loop, once per pair rule (pair_batch)
+    constexpr bool FF = decltype(ff)::value;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+      __syncthreads();  // every wave is done reading the previous tile
 #pragma unroll
-    for (int q = 0; q < LPT; ++q) tile[q * kBlock + threadIdx.x] = stage[q];
-    __syncthreads();
-    if (t + 1 < ntiles) stage_load(t + 1);  // in flight while this tile is consumed
+      for (int q = 0; q < LPT; ++q) tile[q * kBlock + threadIdx.x] = stage[q];
+      __syncthreads();
+      if (t + 1 < ntiles) stage_load(t + 1);  // in flight while this tile is consumed
 
-    const rec_t* src = &tile[jpart * SUB];
-    constexpr int U  = 64 / int(sizeof(rec_t));  // the scalar-stream form's batch: 2 records in f64, 4 in f32
+      const rec_t* src = &tile[jpart * SUB];
+      constexpr int U  = 64 / int(sizeof(rec_t));  // the scalar-stream form's batch: 2 records in f64, 4 in f32
 #pragma unroll 2
-    for (int jj = 0; jj < SUB; jj += U) {
-      rec_t s[U];
+      for (int jj = 0; jj < SUB; jj += U) {
+        rec_t s[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) s[u] = src[jj + u];  // wave-uniform address: LDS broadcast
-      pair_batch<T, D, R, U>(acc, xi, s, pc);
+        for (int u = 0; u < U; ++u) s[u] = src[jj + u];  // wave-uniform address: LDS broadcast
+        pair_batch<T, D, R, U, FF>(acc, xi, s, pc);
+      }
     }
+  };
+  if constexpr (sizeof(T) == 8 || NBODY_F32_FFAR) {
+    if (ffar) run(std::true_type{});
+    else run(std::false_type{});
+  } else {
+    run(std::false_type{});
   }
 
   // combine the JS source-split partials in wave order, then a = c * sum
@@ -176,6 +187,53 @@ __global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restric
   out[j] = r;
 }
 
+// bounding box of all sz positions as order-preserving keys (common.hpp: ext_key), at most 256 blocks
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void extent_kernel(const T* __restrict__ x, uint32_t sz, unsigned long long* __restrict__ ext) {
+  __shared__ double red[2 * D][kWaves];
+  double lo[D], hi[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    lo[k] = double(x[k]);  // body 0: sz >= 1
+    hi[k] = lo[k];
+  }
+  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < sz; j += gridDim.x * kBlock) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      const double v = double(x[uint64_t(j) * D + k]);
+      lo[k]          = v < lo[k] ? v : lo[k];
+      hi[k]          = v > hi[k] ? v : hi[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const double ol = __shfl_xor(lo[k], off, 64), oh = __shfl_xor(hi[k], off, 64);
+      lo[k] = ol < lo[k] ? ol : lo[k];
+      hi[k] = oh > hi[k] ? oh : hi[k];
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      red[k][wave]     = lo[k];
+      red[D + k][wave] = hi[k];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * D) {
+    const bool is_max = threadIdx.x >= D;
+    double v = red[threadIdx.x][0];
+    for (int w = 1; w < kWaves; ++w) {
+      const double o = red[threadIdx.x][w];
+      v = is_max ? (o > v ? o : v) : (o < v ? o : v);
+    }
+    const unsigned long long key = is_max ? ~ext_key(v) : ext_key(v);
+    atomicMin(&ext[threadIdx.x], key);
+  }
+}
+
 template <int JS>
 constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the scalar-stream form
 
@@ -184,7 +242,8 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
                                                                                    const T* __restrict__ x, T* __restrict__ a, T c,
                                                                                    uint32_t sz, uint32_t first, uint32_t count,
                                                                                    uint32_t tiles_per_chunk,
-                                                                                   T* __restrict__ chunk_sums) {
+                                                                                   T* __restrict__ chunk_sums,
+                                                                                   const unsigned long long* __restrict__ ext) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kSgprWaves<JS> / JS;
   constexpr int TB  = TG * 64 * R;
@@ -212,6 +271,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   const uint32_t t0     = blockIdx.y * tiles_per_chunk;
   const uint32_t t1     = min(ntiles, t0 + tiles_per_chunk);
   const pair_consts<T> pc;
+  const bool ffar       = ap_far_mode<D>(ext);
   const uint32_t nsteps = (t1 - t0) * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
   constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
   struct batch_t {
@@ -221,22 +281,31 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   // Two SGPR buffers, each requested (s_load_dwordx16) one compute phase before it is consumed.  Written with inline
   // asm: hipcc folds a loop-carried load from read-only memory back into a load at the loop top and waits for it there.
   // SMEM returns out of order, so the only usable wait is lgkmcnt(0): wait for X, request Y, consume X.
-  sgpr16 A = sload16(batch(0), xi[0][0]), B;
-  for (uint32_t k = 0; k < nsteps; k += 2 * U) {
-    swait(A, acc[0][0]);
-    B = sload16(batch(k + U), xi[0][0]);
-    {
-      const batch_t ba = __builtin_bit_cast(batch_t, A);
-      pair_batch<T, D, R, U>(acc, xi, ba.r, pc);
+  auto run = [&](auto ff) {  // the source stream, once per pair rule (pair_batch)
+    constexpr bool FF = decltype(ff)::value;
+    sgpr16 A = sload16(batch(0), xi[0][0]), B;
+    for (uint32_t k = 0; k < nsteps; k += 2 * U) {
+      swait(A, acc[0][0]);
+      B = sload16(batch(k + U), xi[0][0]);
+      {
+        const batch_t ba = __builtin_bit_cast(batch_t, A);
+        pair_batch<T, D, R, U, FF>(acc, xi, ba.r, pc);
+      }
+      swait(B, acc[0][0]);
+      A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
+      {
+        const batch_t bb = __builtin_bit_cast(batch_t, B);
+        pair_batch<T, D, R, U, FF>(acc, xi, bb.r, pc);
+      }
     }
-    swait(B, acc[0][0]);
-    A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
-    {
-      const batch_t bb = __builtin_bit_cast(batch_t, B);
-      pair_batch<T, D, R, U>(acc, xi, bb.r, pc);
-    }
+    swait(A, acc[0][0]);  // nothing in flight when the wave goes on
+  };
+  if constexpr (sizeof(T) == 8 || NBODY_F32_FFAR) {
+    if (ffar) run(std::true_type{});
+    else run(std::false_type{});
+  } else {
+    run(std::false_type{});
   }
-  swait(A, acc[0][0]);  // nothing in flight when the wave goes on
   if constexpr (JS > 1) {
     if (jpart > 0) {
 #pragma unroll
@@ -292,7 +361,7 @@ struct scratch_buf {
 struct packed_slot {
   int device;
   hipStream_t stream;
-  scratch_buf buf[3];  // 0: packed sources, 1: K1 per-chunk sums, 2: energies work area
+  scratch_buf buf[4];  // 0: packed sources, 1: K1 per-chunk sums, 2: energies work area, 3: bounding-box keys
   std::vector<void*> retired;
 };
 std::mutex g_packed_mu;
@@ -423,6 +492,8 @@ int ap_scratch_reserve(hipStream_t st, int dtype, int dim, uint32_t n) {
   const size_t tsz    = dtype == NBODY_F32 ? 4 : 8;
   const size_t padded = (size_t(n) + kTileJ - 1) / kTileJ * kTileJ;
   if (int r = ap_scratch_get(st, 0, 4 * tsz * padded, &p)) return r;
+  if (n >= kFarMinBodies)
+    if (int r = ap_scratch_get(st, 3, 64, &p)) return r;
   uint32_t chunks = 1, tpc = 0;
   if (auto_split(n) == 8) ap_auto_chunks(n, &chunks, &tpc);
   if (chunks > 1) return ap_scratch_get(st, 1, tsz * size_t(n) * size_t(dim) * chunks, &p);
@@ -447,6 +518,24 @@ int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out) {
   return rc;
 }
 
+// The bounding box of the whole system for ap_far_mode, stream-ordered before K1; nullptr ("dense") below kFarMinBodies
+// and in f32 (see NBODY_F32_FFAR).
+template <typename T, int D>
+static int ap_extent(const nbody_state* s, hipStream_t st, const unsigned long long** out) {
+  *out = nullptr;
+  if (s->sz < kFarMinBodies || (sizeof(T) == 4 && !NBODY_F32_FFAR)) return NBODY_OK;
+  void* q = nullptr;
+  if (int r = ap_scratch_get(st, 3, 64, &q)) return r;
+  NB_HIP(hipMemsetAsync(q, 0xFF, 2 * D * sizeof(unsigned long long), st));
+  uint32_t blocks = (s->sz + kBlock - 1) / kBlock;
+  if (blocks > 256) blocks = 256;
+  hipLaunchKernelGGL((extent_kernel<T, D>), dim3(blocks), dim3(kBlock), 0, st, static_cast<const T*>(s->x), s->sz,
+                     static_cast<unsigned long long*>(q));
+  NB_HIP(hipGetLastError());
+  *out = static_cast<const unsigned long long*>(q);
+  return NBODY_OK;
+}
+
 template <typename T, int D, int R, int JS>
 static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipStream_t st) {
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
@@ -458,12 +547,14 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
     if (int r = ap_scratch_get(st, 1, sizeof(T) * size_t(s->count) * D * plan.chunks, &q)) return r;
     sums = static_cast<T*>(q);
   }
+  const unsigned long long* ext = nullptr;
+  if (int r = ap_extent<T, D>(s, st, &ext)) return r;
   void* scratch = nullptr;
   if (int r = ap_pack_sources(s, st, &scratch)) return r;
   auto* packed = static_cast<src_rec<T, D>*>(scratch);
   hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
                      packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                     plan.tiles_per_chunk, sums);
+                     plan.tiles_per_chunk, sums, ext);
   NB_HIP(hipGetLastError());
   if (sums) {
     const uint64_t n = uint64_t(s->count) * D;
@@ -479,8 +570,10 @@ static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
   constexpr int TB = (kWaves / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
+  const unsigned long long* ext = nullptr;  // the same per-pair rule as the scalar-stream form (bitwise the same result)
+  if (int r = ap_extent<T, D>(s, st, &ext)) return r;
   hipLaunchKernelGGL((all_pairs_force_kernel<T, D, R, JS>), dim3(blocks), dim3(kBlock), 0, st, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count);
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, ext);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -514,10 +607,10 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
   const char* t = sizeof(T) == 8 ? "double" : "float";
   if (p.scalar)
     snprintf(out, len, "all_pairs_force_sgpr_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=%u pair=%s", t, D, p.r, p.js, kTileJ, p.chunks,
-             sizeof(T) == 8 ? "far3/near2" : "rsq+rcp");
+             sizeof(T) == 4 ? "rsq+rcp" : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3");
   else
     snprintf(out, len, "all_pairs_force_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=1 pair=%s", t, D, p.r, p.js, kTileJ,
-             sizeof(T) == 8 ? "far3/near2" : "rsq+rcp");
+             sizeof(T) == 4 ? "rsq+rcp" : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3");
   return NBODY_OK;
 }
 
@@ -709,6 +802,10 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
 #pragma unroll
                 for (int q = 0; q < KS; q += NB) pair_accumulate_far<D, NB>(pt, xg[tt], &src[q], lowest, pc.k15, pc.k1875);
               }
+            } else if constexpr ((NBODY_F32_PAIR & 3) != 0) {
+              constexpr int G = NBODY_K2_TIER_G < KS ? NBODY_K2_TIER_G : KS;
+#pragma unroll
+              for (int q = 0; q < KS; q += G) pair_accumulate_tier<D, G>(pt, xg[tt], &src[q]);
             } else {
 #pragma unroll
               for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);

@@ -114,12 +114,17 @@ inline int dispatch(int dtype, int dim, F&& f) {
 // ---- pair math -----------------------------------------------------------------------------------
 // The reference pair term (src/all_pairs.h:23, src/bvh.h:297,308; dist3 at src/vec.h:249-252) is
 //     m_j * (x_j - x_i) / (pow(r2, 3/2) + eps)
-// i.e. one pow, one add and D divisions per pair.  On gfx950 FP64 transcendentals run at quarter
-// rate and do not overlap the FMA pipe (profiles/r01_valu_rates_microbench.txt), and an IEEE divide is
-// a ~10-instruction sequence, so the kernel evaluates   w = m_j / (r2*sqrt(r2) + eps)   once per pair
-// with two 2^-24 hardware seeds (v_rsq, v_rcp) each polished by one Newton step, then D FMAs.
-// Error budget vs the exact expression: within [-2e-15, +4.1e-15] per term (see NBODY_PAIR_POLISH below;
-// tests/test_gpu_all_pairs.py::test_pair_term_accuracy pins the measured size).
+// i.e. one pow, one add and D divisions per pair.  On gfx950 FP64 transcendentals run at quarter rate and do not overlap
+// the FMA pipe (profiles/r01_valu_rates_microbench.txt), and an IEEE divide is a ~10-instruction sequence, so the kernels
+// evaluate the weight   w = m_j / (r2*sqrt(r2) + eps)   once per pair and then D FMAs.  What is shipped (f64):
+//   * r2 >= 4        weight_far<false>: w = (m y^3)(1 + e(3/2 + 15/8 e)), y = v_rsq_f64(r2), e = 1 - r2 y^2 — no reciprocal,
+//                    and the `+ eps` dropped: eps/r^3 <= 2^-55 there, an eighth of an ulp.   7 ops + 1 transcendental
+//   * 2^-16 <= r2 < 4  weight_far<true>: the same with the first-order term of the eps expansion, - eps y^3.   8 ops + 1
+//   * r2 < 2^-16     weight<3>(): the guarded reciprocal form (the self pair, coincident and very close bodies), <= 2 ulp.
+// Which form a pair takes depends on ITS OWN r2 alone (never on the other lanes of the wave), so a target's sum is bitwise
+// independent of the shard window.  Every form is within 2.5 ulp of the exact term with no bias
+// (tests/test_gpu_all_pairs.py::test_pair_term_accuracy, test_pair_term_two_body_ulps, test_pair_math_adversarial_separations).
+// weight() with NBODY_PAIR_POLISH = 2 is what round 1 shipped everywhere and what the compiler-scheduled tree walks still use.
 //
 // r2 must be > 0: callers fold TINY into the first FMA of r2 (r2 = fma(dx,dx,TINY)), which makes the
 // self term and coincident bodies evaluate to exactly 0 * (finite) = 0 — the value the reference
@@ -175,21 +180,43 @@ struct pair_math<double> {
   // rounding error is left: a = fl(y*y) perturbs e by <= 2^-53 (x 3/2 in w), then y^3, mj*y^3 and the final FMA round once
   // each: <= 2.5 ulp per term, no bias (measured in tests/test_gpu_all_pairs.py::test_pair_term_accuracy).
   static constexpr uint32_t near_hi = 0x3EF00000u;  // high word of 2^-16: r2 below this takes weight()
+  // r2 >= 4: eps*u <= 2^-52 / 8 = 2^-55, an eighth of an ulp of the weight — the term is dropped (weight_far<false>), which
+  // saves the eps*y^3 multiply: 7 full-rate ops + 1 transcendental.  K1 takes that form when EVERY pair of a batch is that far
+  // (one more compare on the minimum it already tracks); in a mixed batch each lane selects eps or 0 by its own r2 (the high
+  // word of DBL_EPSILON is all there is to select: its low word is 0), and fma(p, e, -0) == p * e bit for bit, so a pair's
+  // weight never depends on which other pairs share the batch.
+  static constexpr uint32_t far_hi = 0x40100000u;   // high word of 4.0
   // k15 = 1.5 in a VGPR pair and k1875 = 1.875 in an SGPR pair, held by the caller (pair_consts): neither is an inline
   // constant, and left to itself hipcc feeds a VOP2 v_fmac with the literal and re-creates 1.5 in its accumulator
   // operand with a v_mov per pair.
-  __device__ static __forceinline__ double weight_far(double r2, double mj, double k15, double k1875) {
+  template <bool EPS = true>
+  __device__ static __forceinline__ double weight_far(double r2, double mj, double k15, double k1875, double eps = DBL_EPSILON) {
     double y  = __builtin_amdgcn_rsq(r2);
     double a  = y * y;
     double e  = __builtin_fma(-r2, a, 1.0);
     double y3 = a * y;
     double p  = __builtin_fma(e, k1875, k15);
-    double ey = DBL_EPSILON * y3;
-    double g  = __builtin_fma(p, e, -ey);
+    double g;
+    if constexpr (EPS) g = __builtin_fma(p, e, -(eps * y3));  // eps: DBL_EPSILON, or a lane's own choice of DBL_EPSILON / 0
+    else g = p * e;
     double my = mj * y3;
     return __builtin_fma(my, g, my);
   }
 };
+
+// NBODY_F32_PAIR selects the f32 pair weight of K1 (and K2's NB = 1 chains): 0 = v_rsq_f32 + v_rcp_f32 (3 full-rate ops + 2
+// transcendentals), 1 / 2 = the reciprocal-free far form with the eps expansion to first / second order and a guarded near
+// path, + 4 = an eps-free form when a whole batch has r2 >= 4.  Measured at config 3 and on the galaxy in profiles/r03/
+// f32_pair_forms.txt; the default is what that table says is fastest.
+#ifndef NBODY_F32_PAIR
+  #define NBODY_F32_PAIR 0
+#endif
+// NBODY_F32_FFAR = 1 compiles the sparse-system rule (m y^3 for r2 >= 4) into the f32 kernels too.  Measured A/B on one box
+// (profiles/r03/f32_pair_forms.txt): galaxy N = 262 144 21.17 -> 20.65 ms, but the dense loop of the same kernel 21.23 -> 21.74 ms;
+// shipped off — f32 K1 is then instruction for instruction round 2's kernel.
+#ifndef NBODY_F32_FFAR
+  #define NBODY_F32_FFAR 0
+#endif
 
 template <>
 struct pair_math<float> {
@@ -202,6 +229,24 @@ struct pair_math<float> {
     float y0 = __builtin_amdgcn_rsqf(r2);
     float d3 = __builtin_fmaf(r2, r2 * y0, FLT_EPSILON);
     return __builtin_amdgcn_rcpf(d3) * mj;
+  }
+  // Without the reciprocal: with u = r2^(-3/2) = y^3 (y = v_rsq_f32(r2), 1 ulp),
+  //     mj / (r2^(3/2) + eps) = mj u / (1 + eps u) = mj u (1 - q + q^2 - ...),  q = eps u.
+  // ORDER 1 keeps 1 - q: the dropped q^2 is below 2^-26 (a quarter of an ulp) for q <= 2^-13, i.e. r2 >= 2^-6.67 — threshold 2^-6;
+  // ORDER 2 keeps 1 - q + q^2: q^3 <= 2^-26 for r2 >= 2^-9.6 — threshold 2^-9.  eps is FLT_EPSILON or, where a mixed batch lets
+  // each lane choose by its own r2 (>= 4: eps u <= 2^-26), 0: fma(my, +0, my) == my bit for bit.
+  static constexpr uint32_t far_bits = 0x40800000u;                                    // 4.0f
+  template <int ORDER>
+  static constexpr uint32_t near_bits = ORDER == 1 ? 0x3C800000u : 0x3B000000u;         // 2^-6 / 2^-9 as float bits
+  template <int ORDER>
+  __device__ static __forceinline__ float weight_far(float r2, float mj, float eps = FLT_EPSILON) {
+    const float y  = __builtin_amdgcn_rsqf(r2);
+    const float y3 = (y * y) * y;
+    const float my = mj * y3;
+    if constexpr (ORDER == 0) return my;             // no eps term at all (r2 >= 4 for the whole batch)
+    const float q = eps * y3;
+    if constexpr (ORDER == 1) return __builtin_fmaf(my, -q, my);
+    return __builtin_fmaf(my, __builtin_fmaf(q, q, -q), my);
   }
 };
 
@@ -270,6 +315,43 @@ __device__ __forceinline__ void pair_accumulate_multi(T (&acc)[D], const T (&xi)
   }
 }
 
+// K2 in f32 with a reciprocal-free weight (NBODY_F32_PAIR != 0): G sources against one target, the smallest r2 of the G pairs
+// tracked, one wave-uniform branch into the guarded form per G pairs; each lane keeps per pair what its own r2 asks for.
+#ifndef NBODY_K2_TIER_G
+  #define NBODY_K2_TIER_G 4
+#endif
+template <int D, int G>
+__device__ __forceinline__ void pair_accumulate_tier(float (&acc)[D], const float (&xi)[D], const src_rec<float, D>* s) {
+  constexpr int ORDER = (NBODY_F32_PAIR & 3) ? (NBODY_F32_PAIR & 3) : 2;
+  float d[G][D], r2[G], w[G];
+  uint32_t lowest = 0xffffffffu;
+#pragma unroll
+  for (int b = 0; b < G; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[b][k] = s[b].p[k] - xi[k];
+    float q = pair_math<float>::tiny;
+#pragma unroll
+    for (int k = 0; k < D; ++k) q = __builtin_fmaf(d[b][k], d[b][k], q);
+    r2[b]               = q;
+    const uint32_t bits = __builtin_bit_cast(uint32_t, q);
+    lowest              = bits < lowest ? bits : lowest;
+  }
+#pragma unroll
+  for (int b = 0; b < G; ++b) w[b] = pair_math<float>::template weight_far<ORDER>(r2[b], s[b].m);
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<float>::template near_bits<ORDER>) != 0ull, 0)) {
+#pragma unroll
+    for (int b = 0; b < G; ++b) {
+      const float wn = pair_math<float>::weight(r2[b], s[b].m);
+      w[b]           = __builtin_bit_cast(uint32_t, r2[b]) < pair_math<float>::template near_bits<ORDER> ? wn : w[b];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < G; ++b) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = __builtin_fmaf(w[b], d[b][k], acc[k]);
+  }
+}
+
 // K2 in f64: the same pairs with K1's reciprocal-free weight and NO per-chain branch (a near-pair branch in every chain makes
 // hipcc keep all chains' temporaries alive: 350 VGPRs).  The caller tracks the smallest high word of r2 it has seen and, if a
 // block of pairs held one below 2^-16 (a self pair, a very close body), discards that block's sums and recomputes them with the
@@ -317,19 +399,117 @@ struct pair_consts<double> {
 };
 
 // K1's unit of work: U source records against the R targets of a lane.  acc[r] += w * (x_j - x_i) in source order.
-// f64: every pair takes weight_far() unless some lane of the wave holds a pair closer than 2^-8 (the self pair, a
-// coincident or a very close body: r2 < 2^-16, found with one v_min3_u32 per two pairs on the high words and ONE
-// wave-uniform branch per batch).  Then the wave evaluates weight() too and each lane keeps, pair by pair, the value
-// its own r2 asks for — so a pair's term depends on that pair alone, never on which other targets share the wave:
-// results stay bitwise independent of the shard window.  f32: v_rsq_f32/v_rcp_f32 are 1-ulp instructions, weight() as is.
-template <typename T, int D, int R, int U>
+// `ffar` is a property of the LAUNCH, compiled as two copies of the kernels' source loops — inside ONE loop hipcc hoists the
+// common head of the two rules above the branch and interleaves the f32 pair chains, which costs 15 % (24.4 against 21.2 ms at
+// config 3) — (ap_far_mode: the whole system's bounding box says that few batches can hold a pair closer
+// than 2; every rank and every shard window of one system computes the same value) and selects the per-pair rule:
+//   dense (ffar false): f64 weight_far<true> for r2 >= 2^-16, weight<3>() below; f32 weight().
+//   sparse (ffar true): f64 weight_far<false> for r2 >= 4, weight_far<true> in [2^-16, 4), weight<3>() below;
+//                       f32 m y^3 for r2 >= 4, weight() below.
+// The smallest r2 of the batch (one v_min3_u32 per two pairs on the high words) decides with one wave-uniform branch which code
+// runs; in a mixed batch each lane keeps, pair by pair, what its own r2 asks for.  Under a given rule a pair's term depends on
+// that pair alone, never on which other targets share the wave: results stay bitwise independent of the shard window.
+// (In the dense regime the sparse rule would put every batch on the mixed path: measured 3.20 against 2.62 ms at config 2.)
+template <typename T, int D, int R, int U, bool ffar>
 __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], const src_rec<T, D> (&s)[U],
                                            const pair_consts<T>& pc) {
-  if constexpr (sizeof(T) == 4) {
+  if constexpr (sizeof(T) == 4 && (NBODY_F32_PAIR & 3) == 0) {
+    if constexpr (!ffar) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], s[u]);
+    } else {
+      // sparse system (ap_far_mode): a pair at r2 >= 4 takes m y^3 — eps u <= 2^-26 there, an eighth of an ulp — and every other
+      // pair the guarded form above, by ITS OWN r2; a batch whose pairs are all that far never issues the reciprocal
+      T d[U][R][D], r2[U][R], w[U][R];
+      uint32_t lowest = 0xffffffffu;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) d[u][r][k] = s[u].p[k] - xi[r][k];
+          T q = pair_math<T>::tiny;
+#pragma unroll
+          for (int k = 0; k < D; ++k) q = __builtin_elementwise_fma(d[u][r][k], d[u][r][k], q);
+          r2[u][r]            = q;
+          const uint32_t bits = __builtin_bit_cast(uint32_t, q);
+          lowest              = bits < lowest ? bits : lowest;
+        }
+      T y[U][R];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          y[u][r] = __builtin_amdgcn_rsqf(r2[u][r]);
+          w[u][r] = s[u].m * ((y[u][r] * y[u][r]) * y[u][r]);
+        }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::far_bits) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const T d3 = __builtin_fmaf(r2[u][r], r2[u][r] * y[u][r], FLT_EPSILON);  // == pair_math<float>::weight
+            const T wn = __builtin_amdgcn_rcpf(d3) * s[u].m;
+            w[u][r]    = __builtin_bit_cast(uint32_t, r2[u][r]) < pair_math<T>::far_bits ? wn : w[u][r];
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc[r][k] = __builtin_elementwise_fma(w[u][r], d[u][r][k], acc[r][k]);
+    }
+  } else if constexpr (sizeof(T) == 4) {
+    constexpr int ORDER  = NBODY_F32_PAIR & 3;
+    constexpr bool FFAST = (NBODY_F32_PAIR & 4) != 0;
+    T d[U][R][D], r2[U][R], w[U][R];
+    uint32_t lowest = 0xffffffffu;
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int r = 0; r < R; ++r) pair_accumulate<T, D>(acc[r], xi[r], s[u]);
+      for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) d[u][r][k] = s[u].p[k] - xi[r][k];
+        T q = pair_math<T>::tiny;
+#pragma unroll
+        for (int k = 0; k < D; ++k) q = __builtin_elementwise_fma(d[u][r][k], d[u][r][k], q);
+        r2[u][r]            = q;
+        const uint32_t bits = __builtin_bit_cast(uint32_t, q);
+        lowest              = bits < lowest ? bits : lowest;
+      }
+    if (FFAST && __builtin_amdgcn_ballot_w64(lowest < pair_math<T>::far_bits) == 0ull) {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::template weight_far<0>(r2[u][r], s[u].m);
+    } else {
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          T eps = FLT_EPSILON;
+          if constexpr (FFAST) eps = __builtin_bit_cast(uint32_t, r2[u][r]) < pair_math<T>::far_bits ? FLT_EPSILON : T(0);
+          w[u][r] = pair_math<T>::template weight_far<ORDER>(r2[u][r], s[u].m, eps);
+        }
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::template near_bits<ORDER>) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const T wn = pair_math<T>::weight(r2[u][r], s[u].m);
+            w[u][r]    = __builtin_bit_cast(uint32_t, r2[u][r]) < pair_math<T>::template near_bits<ORDER> ? wn : w[u][r];
+          }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) acc[r][k] = __builtin_elementwise_fma(w[u][r], d[u][r][k], acc[r][k]);
   } else {
     T d[U][R][D], r2[U][R], w[U][R];
     uint32_t lowest = 0xffffffffu;
@@ -346,19 +526,50 @@ __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], 
         const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, q) >> 32);
         lowest            = hi < lowest ? hi : lowest;
       }
+    if constexpr (!ffar) {
+      // dense system: every pair takes weight_far<true> unless some lane holds one below 2^-16
 #pragma unroll
-    for (int u = 0; u < U; ++u)
+      for (int u = 0; u < U; ++u)
 #pragma unroll
-      for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::weight_far(r2[u][r], s[u].m, pc.k15, pc.k1875);
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::near_hi) != 0ull, 0)) {
+        for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::template weight_far<true>(r2[u][r], s[u].m, pc.k15, pc.k1875);
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::near_hi) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
+            const T wn        = pair_math<T>::template weight<3>(r2[u][r], s[u].m);  // rare: take the <= 2 ulp form
+            w[u][r]           = hi < pair_math<T>::near_hi ? wn : w[u][r];
+          }
+      }
+    } else if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::far_hi) == 0ull, 1)) {
+      // sparse system, every pair of the batch at r2 >= 4: no eps term at all
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::template weight_far<false>(r2[u][r], s[u].m, pc.k15, pc.k1875);
+    } else {
+      // sparse system, some pair is closer: every lane keeps, pair by pair, what ITS r2 asks for — eps or 0 in the far form ...
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-          const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
-          const T wn        = pair_math<T>::template weight<3>(r2[u][r], s[u].m);  // rare: take the <= 2 ulp form
-          w[u][r]           = hi < pair_math<T>::near_hi ? wn : w[u][r];
+          const uint32_t hi  = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
+          const uint32_t ehi = hi < pair_math<T>::far_hi ? 0x3CB00000u : 0u;  // high word of DBL_EPSILON (its low word is 0)
+          const T eps        = __builtin_bit_cast(T, (unsigned long long)ehi << 32);
+          w[u][r]            = pair_math<T>::template weight_far<true>(r2[u][r], s[u].m, pc.k15, pc.k1875, eps);
         }
+      // ... and the guarded reciprocal form below 2^-16 (the self pair, coincident or very close bodies)
+      if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::near_hi) != 0ull, 0)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int r = 0; r < R; ++r) {
+            const uint32_t hi = uint32_t(__builtin_bit_cast(unsigned long long, r2[u][r]) >> 32);
+            const T wn        = pair_math<T>::template weight<3>(r2[u][r], s[u].m);
+            w[u][r]           = hi < pair_math<T>::near_hi ? wn : w[u][r];
+          }
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u)
@@ -370,6 +581,32 @@ __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], 
 }
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+// ---- the system's bounding box, for ap_far_mode -------------------------------------------------------------------
+// Coordinates are reduced with integer atomicMin on order-preserving keys (a double's bits, sign-flipped): order-free, so
+// the result is the same whatever the launch shape.  ext[k] = key(min_k), ext[D + k] = ~key(max_k): all six are minima and
+// one memset of 0xFF initialises them.
+__host__ __device__ inline unsigned long long ext_key(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__host__ __device__ inline double ext_value(unsigned long long key) {
+  const unsigned long long b = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
+  return __builtin_bit_cast(double, b);
+}
+constexpr uint32_t kFarMinBodies = 32768;  // below this the rule is "dense" by definition (from sz alone: nothing is measured)
+// Sparse iff a batch of 256 pairs rarely holds one closer than 2: with the bodies spread over the box of volume V the expected
+// number of such pairs per batch is 256 * (4/3 pi 8) / V (256 * 4 pi / A in 2D); the rule asks for < 0.05.  Real systems are
+// clumpier than their box (the galaxy: 6 % of the batches at V = 4e6) — the rule only has to tell a unit cube from a galaxy.
+template <int D>
+__device__ __forceinline__ bool ap_far_mode(const unsigned long long* __restrict__ ext) {
+  if (ext == nullptr) return false;
+  double vol = 1.0;
+#pragma unroll
+  for (int k = 0; k < D; ++k) vol *= ext_value(~ext[D + k]) - ext_value(ext[k]);
+  const bool far = vol >= (D == 3 ? 1.7e5 : 6.4e4);
+  return __builtin_amdgcn_readfirstlane(int(far)) != 0;
+}
 
 // ---- scalar-stream helpers (K1's default form, the energies) ------------------------------------------------
 constexpr int kTileJ = 512;  // source records per tile (fixed: the rounding order of K1 depends on it)
@@ -400,7 +637,7 @@ inline int check_tuning(int split, int tpt, int path) {
 // all_pairs.hip: per-(device, stream) packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
 int ap_scratch_reserve(hipStream_t st, int dtype, int dim, uint32_t n);
 void ap_scratch_release(hipStream_t st);
-int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 chunk sums, 2 energies
+int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 chunk sums, 2 energies, 3 bounding-box keys
 int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk);
 

@@ -9,7 +9,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 cases = [("f64", nb.F64, "uniform", 65536, None), ("f64", nb.F64, "galaxy", 100000, None), ("f64", nb.F64, "galaxy", 262144, None),
          ("f64", nb.F64, "galaxy", 1 << 20, (1 << 20) // 8), ("f64", nb.F64, "galaxy", 1 << 20, None),
          ("f64", nb.F64, "uniform", 10000, None), ("f64", nb.F64, "uniform", 30000, None),
-         ("f32", nb.F32, "uniform", 262144, None), ("f32", nb.F32, "uniform", 100000, None)]
+         ("f32", nb.F32, "uniform", 262144, None), ("f32", nb.F32, "uniform", 100000, None),
+         ("f32", nb.F32, "galaxy", 262144, None), ("f64", nb.F64, "uniform", 262144, None), ("f64", nb.F64, "galaxy", 65536, None)]
 out = []
 for tname, dt, wl, n, count in cases:
     dev = nb.DeviceSystem.from_host(nb.build_model(dt, 3, wl, n))

@@ -576,14 +576,14 @@ __device__ __forceinline__ void rec_wait(V& v) {
 // item = group | first lane << 20 | last lane << 26.  Nothing but grouping and start order changes: a body's result depends
 // on the tree and that body alone.
 constexpr uint32_t kOrderMax = 8192;  // groups per XCD range one block handles (N <= 4.2M bodies); more: plain index order
-constexpr uint32_t kSplitMax = 512;   // groups per XCD range that may be cut
+constexpr uint32_t kSplitMax = 2048;  // groups per XCD range that may be cut
 __host__ __device__ __forceinline__ void xcd_range(uint32_t xcd, uint32_t nblocks, uint32_t* start, uint32_t* len) {
   const uint32_t q = nblocks / 8u, r = nblocks % 8u;
   *start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
   *len   = q + (xcd < r ? 1u : 0u);
 }
-__host__ __device__ __forceinline__ uint32_t split_budget(uint32_t len) {
-  const uint32_t b = len / 16u;
+__host__ __device__ __forceinline__ uint32_t split_budget(uint32_t len, uint32_t den = 16u) {
+  const uint32_t b = len / den;
   return len > kOrderMax ? 0u : (b < kSplitMax ? b : kSplitMax);
 }
 __device__ __forceinline__ uint32_t pack_item(uint32_t group, uint32_t lo, uint32_t hi) { return group | (lo << 20) | (hi << 26); }
@@ -591,7 +591,7 @@ __device__ __forceinline__ uint32_t pack_item(uint32_t group, uint32_t lo, uint3
 // items of XCD x live at items[x * stride ...], nitems[x] of them; stride = longest range + its budget
 __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restrict__ sorted_keys, uint32_t first, uint32_t count,
                                                           uint32_t* __restrict__ items, uint32_t* __restrict__ nitems,
-                                                          uint32_t nblocks, uint32_t stride) {
+                                                          uint32_t nblocks, uint32_t stride, uint32_t den) {
   __shared__ uint8_t lvl[kOrderMax];
   __shared__ uint32_t hist[65], tsum[1024], outl[kSplitMax];
   __shared__ uint32_t thr, nout;
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
   }
   __syncthreads();
   if (t == 0) {  // the smallest level such that at most split_budget(len) groups lie at or above it
-    const uint32_t budget = split_budget(len);
+    const uint32_t budget = split_budget(len, den);
     uint32_t acc = 0, l = 64;
     while (l > 0 && acc + hist[l] <= budget) acc += hist[l--];
     thr = l + 1;
@@ -678,7 +678,7 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
                                                             const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                             uint32_t count, T theta2, uint32_t nlevels,
                                                             uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
-                                                            const uint32_t* __restrict__ nitems, uint32_t stride) {
+                                                            const uint32_t* __restrict__ nitems, uint32_t stride, uint32_t parts) {
   constexpr uint32_t DONE = 0xffffffffu;
   constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
   // work item of this block: with an item list, the XCD it runs on (block index mod 8) owns one list (bvh_items_kernel)
@@ -690,6 +690,10 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
     group   = it & 0xfffffu;
     lane_lo = (it >> 20) & 63u;
     lane_hi = it >> 26;
+  } else if (parts > 1u) {  // every group as `parts` equal lane ranges (small systems: see force_run)
+    lane_lo = (group % parts) * (64u / parts);
+    lane_hi = lane_lo + 64u / parts - 1u;
+    group /= parts;
   }
   const uint32_t base = group * (64u * BPL) + threadIdx.x;
   const pair_consts<T> pc;
@@ -1097,7 +1101,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
                                                                  const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
                                                                  uint32_t count, T theta2, uint32_t nlevels,
                                                                  uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
-                                                                 const uint32_t* __restrict__ nitems, uint32_t stride) {
+                                                                 const uint32_t* __restrict__ nitems, uint32_t stride, uint32_t parts) {
   static_assert(sizeof(tree_rec<T>) == 8 * sizeof(T), "the step program addresses records of 8 scalars");
   // work item of this block, as in bvh_force_wave_kernel
   uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
@@ -1108,6 +1112,10 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     group   = it & 0xfffffu;
     lane_lo = (it >> 20) & 63u;
     lane_hi = it >> 26;
+  } else if (parts > 1u) {  // every group as `parts` equal lane ranges (small systems: see force_run)
+    lane_lo = (group % parts) * (64u / parts);
+    lane_hi = lane_lo + 64u / parts - 1u;
+    group /= parts;
   }
   const uint32_t local = group * 64u + threadIdx.x;
   const bool valid     = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
@@ -1277,7 +1285,8 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   // gathers pay for every entry (10^5 bodies after 400-1000 steps: sweep 1.7-2.1 ms, per-lane 3.0-3.7 ms per traversal).
   // f64 below 5*10^4: the first steps of the galaxy favour the per-lane form by 7 % (4*10^4) to 20 % (10^4), its evolved states the
   // sweep by 25-40 % (whole 1000-step runs, sweep / per-lane: 0.86 / 0.91 s at 10^4, 0.99 / 1.07 at 2*10^4, 1.16 / 1.47 at 3*10^4)
-  const uint32_t crossover = sizeof(T) == 8 ? 30000u : 180000u;
+  // f64 with the finer work items of small systems (below): the sweep wins from the smallest sizes measured (10^4: 0.27 against 0.33 ms)
+  const uint32_t crossover = sizeof(T) == 8 ? 4096u : 180000u;
   int traversal = t->traversal;
   if (const char* e = experiment_env("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // -DNBODY_EXPERIMENTS builds only
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
@@ -1298,18 +1307,34 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   dim3(blocks), dim3(64), 0, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, \
    s->count, th2, t->nlevels, t->counters
   const uint32_t *items = nullptr, *nitems = nullptr;
-  uint32_t stride = 0, wave_blocks = blocks;
+  uint32_t stride = 0, wave_blocks = blocks, parts = 1;
   const char* oe = experiment_env("NBODY_K9_ORDER");  // -DNBODY_EXPERIMENTS builds: 0 = one block per group in index order
-  if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && t->launch_order == 0 && !(oe && oe[0] == '0')) {
-    // Work items (bvh_items_kernel): groups that straddle a jump of the key order are cut in two and start first.  Measured
+  const bool plain = t->launch_order != 0 || (oe && oe[0] == '0');
+  // Finer work items (profiles/r03/k9_parts.txt, ms per traversal of the initial galaxy, f64): every group swept as `parts` equal
+  // lane ranges side by side has shorter unions (16 Hilbert-adjacent walks: 5.7k steps against 7.4k for 64 at config 4) but
+  // more of them.  That pays only while the chip is nearly empty — N = 10^4: 0.40 (1 part) / 0.36 (4) / 0.27 (8), per-lane form
+  // 0.33; N = 3*10^4: 0.64 / 0.56 / 0.56, per-lane 0.58 — and costs from 6*10^4 bodies on (10^5: 1.06 / 1.62 / 1.86; 10^6: 6.96 /
+  // 16.6 / 28.2).  The key-jump cutter below behaves the same way at N = 10^6: 1/16 of the groups cut 6.97 ms, 1/8 7.11, 1/4 7.39,
+  // 1/2 7.84, all 10.3 — the filling and draining of a launch cannot be bought back with more, shorter items.
+  if (wave && bpl == 1 && !plain) {
+    parts = blocks <= 320u ? 8u : (blocks <= 640u ? 4u : 1u);
+    if (const char* pe = experiment_env("NBODY_K9_PARTS")) parts = uint32_t(atoi(pe));  // -DNBODY_EXPERIMENTS builds only
+    if (parts != 1u && parts != 2u && parts != 4u && parts != 8u && parts != 16u) parts = 1u;
+  }
+  if (parts > 1u) {
+    wave_blocks = blocks * parts;
+  } else if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && !plain) {
+    // Work items (bvh_items_kernel): groups that straddle a jump of the key order are cut in two and started first.  Measured
     // in the CLI's step loop (ms per whole bvh step; index order / start order only / start order + cut): N = 10^6 8.05 / 7.4 /
     // 7.4, 5*10^5 5.3 / 4.6 / 4.3.  The sorted keys are in keys[1] (8 radix passes end in the buffer they started from).
+    uint32_t den = 16;
+    if (const char* de = experiment_env("NBODY_K9_SPLIT")) den = uint32_t(atoi(de)) ? uint32_t(atoi(de)) : 16u;  // experiments only
     uint32_t s0, l0;
     xcd_range(0, blocks, &s0, &l0);  // XCD 0 has the longest range
-    stride      = l0 + split_budget(l0);
+    stride      = l0 + split_budget(l0, den);
     wave_blocks = 8u * stride;       // blocks are dealt round-robin over the XCDs: 8 lists of up to `stride` items
     hipLaunchKernelGGL(bvh_items_kernel, dim3(8), dim3(1024), 0, st, t->keys[1], s->first, s->count, t->order, t->order_n, blocks,
-                       stride);
+                       stride, den);
     NB_HIP(hipGetLastError());
     items  = t->order;
     nitems = t->order_n;
@@ -1318,7 +1343,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const uint32_t lds = le ? uint32_t(atoi(le)) : 0u;
 #define NB_WARGS                                                                                                             \
   dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
-   s->first, s->count, th2, t->nlevels, t->counters, items, nitems, stride
+   s->first, s->count, th2, t->nlevels, t->counters, items, nitems, stride, parts
   if (wave && bpl == 2) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
@@ -1399,7 +1424,7 @@ extern "C" int nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
-  NB_ALLOC(t->order, sizeof(uint32_t) * (((size_t(n) + 63) / 64 / 8 + 1) * 17 / 16 + 8) * 8);  // 8 x (longest range + budget)
+  NB_ALLOC(t->order, sizeof(uint32_t) * (((size_t(n) + 63) / 64 / 8 + 1) * 2 + 8) * 8);  // 8 x (longest range + the largest budget)
   NB_ALLOC(t->order_n, sizeof(uint32_t) * 8);
 #undef NB_ALLOC
   *out = t;

@@ -70,7 +70,7 @@ typedef struct nbody_state {
 
 /* ABI version of this header/library pair: major * 1000 + minor.  Bindings should refuse a different major.
  * 2.0: nbody_state.tuning; the collective (nbody_comm_*), shard windows on contexts, per-device guards.
- * 2.1: nbody_bvh_create_on / nbody_octree_create_on (explicit device), nbody_octree_set_walk, nbody_octree_set_step_budget,
+ * 2.1: nbody_bvh_create_on / nbody_octree_create_on (explicit device), nbody_octree_set_walk, nbody_octree_set_build, nbody_octree_set_step_budget,
  *      nbody_bvh_set_launch_order;
  *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)). */
 #define NBODY_HIP_ABI_VERSION 2001
@@ -177,6 +177,11 @@ void nbody_octree_destroy(nbody_octree* t);
 /* Scheduling form of the walk: 0 = auto, 1 = the compiler-scheduled kernel, 2 = the visit round written as ISA (fails where that
  * form does not exist).  Same tests, same arithmetic, same order: bitwise identical accelerations and counters. */
 int  nbody_octree_set_walk(nbody_octree* t, int mode);
+/* How the breadth-first build and the multipole pass are launched: 1 = one launch per tree level (21 + 21 in 3D); 0 = auto:
+ * one launch per level the tree used at the last nbody_octree_info (+ 2) and ONE launch for all deeper levels, which walks
+ * them behind a grid barrier (at most one block per compute unit) and normally finds them empty; 2 = every level behind
+ * the grid barrier (measured slower on MI355X, kept as a cross-check).  Same tree, same monopoles bit for bit. */
+int  nbody_octree_set_build(nbody_octree* t, int mode);
 /* Visit rounds one body's walk may make before it is abandoned and nbody_octree_info reports it (never spin on a damaged
  * tree).  0 = the default: the node pool size, which no walk of a well-formed tree reaches. */
 int  nbody_octree_set_step_budget(nbody_octree* t, uint32_t steps);

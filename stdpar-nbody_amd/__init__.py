@@ -49,7 +49,7 @@ ABI_SYMBOLS = [
     "nbody_octree_create", "nbody_octree_destroy", "nbody_octree_clear", "nbody_octree_compute_bounds", "nbody_octree_insert",
     "nbody_octree_compute_tree", "nbody_octree_compute_force", "nbody_octree_info", "nbody_octree_enable_counters",
     "nbody_octree_read_counters", "nbody_bvh_compute_force", "nbody_bvh_read", "nbody_bvh_enable_counters", "nbody_bvh_set_traversal", "nbody_bvh_nnodes", "nbody_create",
-    "nbody_bvh_create_on", "nbody_octree_create_on", "nbody_octree_set_walk", "nbody_octree_set_step_budget", "nbody_bvh_set_launch_order",
+    "nbody_bvh_create_on", "nbody_octree_create_on", "nbody_octree_set_walk", "nbody_octree_set_build", "nbody_octree_set_step_budget", "nbody_bvh_set_launch_order",
     "nbody_destroy", "nbody_upload", "nbody_download", "nbody_ctx_state", "nbody_ctx_stream", "nbody_stream_sync",
     "nbody_graph_begin", "nbody_graph_end", "nbody_graph_launch", "nbody_graph_destroy",
     "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
@@ -283,6 +283,10 @@ class Octree:
         self.h = C.c_void_p()
         self.dtype, self.dim, self.n = dtype, dim, n
         _check(lib().nbody_octree_create_on(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
+
+    def set_build(self, mode):
+        """0 auto, 1 one launch per tree level, 2 all levels in one launch (grid barrier); bitwise identical trees."""
+        _check(lib().nbody_octree_set_build(self.h, mode))
 
     def set_step_budget(self, steps):
         """Visit rounds a body's walk may make before it is abandoned and info() raises (0 = the node pool size)."""

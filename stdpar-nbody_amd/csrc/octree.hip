@@ -32,7 +32,7 @@ namespace nbody {
 constexpr int kOB            = 256;
 constexpr uint32_t kOtEmpty  = 0xffffffffu;  // src/octree.h:37
 constexpr uint32_t kOtBody   = 0xfffffffeu;  // src/octree.h:38
-constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u, kFlagWalk = 8u;
+constexpr uint32_t kFlagDepth = 1u, kFlagCapacity = 2u, kFlagStack = 4u, kFlagWalk = 8u, kFlagBarrier = 16u;
 constexpr int kOtDeepLevels = 128;  // total depth the deep build follows before it calls the bodies coincident
 // its DFS stack: the cells on the current path stay for their second visit (<= kOtDeepLevels), plus the waiting siblings — the
 // biggest child of a cell is entered LAST, so siblings wait only along the <= log2(n) levels where the path entered a smaller child
@@ -278,6 +278,7 @@ template <typename T, int D>
 __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const T* __restrict__ x, ot_tree<T, D> tree,
                                      ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count) {
   if (threadIdx.x < uint32_t(kMaxLevels<D> + 2)) lvl_count[threadIdx.x] = 0;
+  if (threadIdx.x < 2) lvl_count[kMaxLevels<D> + 3 + threadIdx.x] = 0;  // the grid-barrier counters of the two all-level kernels
   if (threadIdx.x == 0) {  // (the overflow flags behind lvl_count are sticky: nbody_octree_info reports and clears them)
     ot_node<T> r;
 #pragma unroll
@@ -304,22 +305,48 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
 // the next level's cell list with ONE counter bump per 1024-thread block: returning same-address atomics complete at
 // ~12 ns each on this chip whatever else the kernel does (one per wave made the widest level 402 us, 37k atomics).
 constexpr int kOBuild = 1024;
+
+// Grid-wide barrier of a kernel whose blocks are all resident (one block per CU at most: ot_grid_blocks).  Every wave reaches an
+// exit: a block that has waited kBarrierSpins polls (seconds; e.g. the GPU is shared and its peers never got a slot) raises
+// kFlagBarrier, which nbody_octree_info reports, and the kernel's level loop ends on every block at its next check.
+constexpr uint32_t kBarrierSpins = 4u << 20;
+__device__ __forceinline__ bool ot_grid_barrier(uint32_t* counter, uint32_t& epoch, uint32_t* flags) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();  // release: this block's writes of the level before the arrival
+    const uint32_t target = (epoch + 1u) * gridDim.x;
+    atomicAdd(counter, 1u);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > kBarrierSpins) {
+        atomicOr(flags, kFlagBarrier);
+        break;
+      }
+    }
+    __threadfence();  // acquire: the other blocks' writes (invalidates this CU's vector L1)
+  }
+  ++epoch;
+  __syncthreads();
+  return (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kFlagBarrier) == 0u;
+}
+__device__ __forceinline__ uint32_t ot_count(const uint32_t* lvl_count, int level) {  // written by other blocks of this kernel
+  return __hip_atomic_load(lvl_count + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One block's share of one level: cells [vblock * 1024 / 2^D, ...) of `count`.  `cells`, `lvl_count` and the tree are written by
+// other blocks during the all-level kernel, so nothing here is __restrict__ and the counters are read with agent-scope loads.
 template <typename T, int D>
-__global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
-                                                                 const uint32_t* __restrict__ sidx, const T* __restrict__ m,
-                                                                 const T* __restrict__ x, ot_tree<T, D> tree,
-                                                                 ot_cell* __restrict__ cells, uint32_t* __restrict__ lvl_count,
-                                                                 uint32_t* __restrict__ flags, uint32_t capacity,
-                                                                 uint32_t max_cells) {
+__device__ __forceinline__ void ot_build_level_body(int level, uint32_t vblock, uint32_t count, uint32_t base,
+                                                    const uint64_t* __restrict__ skeys, const uint32_t* __restrict__ sidx,
+                                                    const T* __restrict__ m, const T* __restrict__ x, ot_tree<T, D> tree,
+                                                    ot_cell* cells, uint32_t* lvl_count, uint32_t* flags, uint32_t capacity,
+                                                    uint32_t max_cells) {
   constexpr uint32_t NCH = 1u << D;
   __shared__ uint32_t wave_first[kOBuild / 64];
   __shared__ uint32_t block_first;
-  const uint32_t count = lvl_count[level];
-  if (blockIdx.x * (kOBuild / NCH) >= count) return;  // whole blocks beyond this level's cells
-  const uint32_t tid = blockIdx.x * kOBuild + threadIdx.x;
+  const uint32_t tid = vblock * kOBuild + threadIdx.x;
   const uint32_t k = tid / NCH, c = tid % NCH;
-  uint32_t base = 0;  // cells of the shallower levels = rank of this level's first cell
-  for (int j = 0; j < level; ++j) base += lvl_count[j];
   const uint32_t rank = base + k;
   const uint32_t fc   = 1u + rank * NCH;  // its sibling group (the reference's bump allocator hands out the same shape)
   bool live           = k < count;        // lane groups of a cell stay together
@@ -368,6 +395,7 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
   const bool split      = live && end - lo >= 2;
   const uint64_t voters = __ballot(split);
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  __syncthreads();  // (the previous share of this block is done with the two shared words)
   if (lane == 0) wave_first[wave] = uint32_t(__builtin_popcountll(voters));
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -385,6 +413,44 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
         base + count + block_first + wave_first[wave] + uint32_t(__builtin_popcountll(voters & ((1ull << lane) - 1ull)));
     if (pos < max_cells) cells[pos] = ot_cell{ci, lo, end};
     else atomicOr(flags, kFlagCapacity);
+  }
+}
+
+// one launch per level (kept as the cross-check of the all-level kernel: nbody_octree_set_build)
+template <typename T, int D>
+__global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, const uint64_t* __restrict__ skeys,
+                                                                 const uint32_t* __restrict__ sidx, const T* __restrict__ m,
+                                                                 const T* __restrict__ x, ot_tree<T, D> tree, ot_cell* cells,
+                                                                 uint32_t* lvl_count, uint32_t* flags, uint32_t capacity,
+                                                                 uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  const uint32_t count = lvl_count[level];
+  if (blockIdx.x * (kOBuild / NCH) >= count) return;  // whole blocks beyond this level's cells
+  uint32_t base = 0;  // cells of the shallower levels = rank of this level's first cell
+  for (int j = 0; j < level; ++j) base += lvl_count[j];
+  ot_build_level_body<T, D>(level, blockIdx.x, count, base, skeys, sidx, m, x, tree, cells, lvl_count, flags, capacity, max_cells);
+}
+
+// All levels in ONE launch: the step loop of a small system is bound by its ~75 dependent launches (4.6 us each inside a
+// recorded step: half of the octree step at N = 10^5).  A grid of at most one 1024-thread block per CU walks the levels with a
+// grid barrier between them and stops at the first level without cells.
+template <typename T, int D>
+__global__ __launch_bounds__(kOBuild) void ot_build_all_levels_kernel(const uint64_t* __restrict__ skeys,
+                                                                      const uint32_t* __restrict__ sidx, const T* __restrict__ m,
+                                                                      const T* __restrict__ x, ot_tree<T, D> tree, ot_cell* cells,
+                                                                      uint32_t* lvl_count, uint32_t* flags, uint32_t capacity,
+                                                                      uint32_t max_cells, int first_level) {
+  constexpr uint32_t NCH = 1u << D;
+  uint32_t* counter = lvl_count + (kMaxLevels<D> + 3);
+  uint32_t epoch = 0, base = 0;
+  for (int j = 0; j < first_level; ++j) base += ot_count(lvl_count, j);  // levels built by earlier launches
+  for (int level = first_level; level < kMaxLevels<D>; ++level) {
+    const uint32_t count = ot_count(lvl_count, level);  // final: every block has passed the barrier behind level - 1
+    if (count == 0) break;                              // (the same value on every block: they leave together)
+    for (uint32_t vb = blockIdx.x; vb * (kOBuild / NCH) < count; vb += gridDim.x)
+      ot_build_level_body<T, D>(level, vb, count, base, skeys, sidx, m, x, tree, cells, lvl_count, flags, capacity, max_cells);
+    base += count;
+    if (!ot_grid_barrier(counter, epoch, flags)) break;
   }
 }
 
@@ -546,19 +612,11 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
 
 // ---- multipoles (src/octree.h:205-216) ---------------------------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_tree<T, D> tree,
-                                                                 const ot_cell* __restrict__ cells,
-                                                                 const uint32_t* __restrict__ lvl_count) {
+__device__ __forceinline__ void ot_multipole_cell(ot_tree<T, D> tree, uint32_t node) {
 #pragma clang fp contract(off)
   constexpr uint32_t NCH = 1u << D;
-  const uint32_t count   = lvl_count[level];
-  const uint32_t k       = blockIdx.x * kOB + threadIdx.x;
-  if (k >= count) return;
-  uint32_t base = 0;
-  for (int j = 0; j < level; ++j) base += lvl_count[j];
-  const uint32_t node = cells[base + k].node;
-  ot_node<T> pn       = tree.get(node);
-  const uint32_t fc   = pn.fc;
+  ot_node<T> pn     = tree.get(node);
+  const uint32_t fc = pn.fc;
   if (fc == kOtEmpty || fc == kOtBody) return;  // only after an overflow flag
   T mass = T(0), xx[D];
 #pragma unroll
@@ -573,6 +631,41 @@ __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_t
   for (int q = 0; q < D; ++q) pn.p[q] = xx[q] / mass;
   pn.m = mass;
   tree.put(node, pn);
+}
+
+// one launch per level (the cross-check of the all-level kernel)
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_tree<T, D> tree,
+                                                                 const ot_cell* __restrict__ cells,
+                                                                 const uint32_t* __restrict__ lvl_count) {
+  const uint32_t count = lvl_count[level];
+  const uint32_t k     = blockIdx.x * kOB + threadIdx.x;
+  if (k >= count) return;
+  uint32_t base = 0;
+  for (int j = 0; j < level; ++j) base += lvl_count[j];
+  ot_multipole_cell<T, D>(tree, cells[base + k].node);
+}
+
+// All levels, deepest first, in ONE launch with a grid barrier between non-empty levels (see ot_build_all_levels_kernel).  The
+// cell lists and level counts are final here (the build is an earlier launch); only the tree's monopoles change.
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                                      const uint32_t* __restrict__ lvl_count, uint32_t* counter,
+                                                                      uint32_t* flags, int lowest_level) {
+  uint32_t cnt[kMaxLevels<D>], total = 0;
+#pragma unroll
+  for (int l = 0; l < kMaxLevels<D>; ++l) {
+    cnt[l] = lvl_count[l];
+    total += cnt[l];
+  }
+  uint32_t epoch = 0, base = total;
+  for (int l = kMaxLevels<D> - 1; l >= lowest_level; --l) {
+    const uint32_t count = cnt[l];
+    if (count == 0) continue;
+    base -= count;
+    for (uint32_t k = blockIdx.x * kOB + threadIdx.x; k < count; k += gridDim.x * kOB) ot_multipole_cell<T, D>(tree, cells[base + k].node);
+    if (l > lowest_level && !ot_grid_barrier(counter, epoch, flags)) break;
+  }
 }
 
 // ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------
@@ -1155,6 +1248,9 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
 struct nbody_octree {
   int dtype = 0, dim = 0, device = 0;  // device: nbody_octree_create_on's (nbody_octree_create: the current one); every call runs there
   int walk = 0;                        // nbody_octree_set_walk: 0 auto, 1 compiler-scheduled kernel, 2 the visit round as ISA
+  int build = 0;                       // nbody_octree_set_build: 0 / 1 = one launch per level, 2 = all levels in one launch (grid barrier)
+  int depth_hint = 64;                 // levels launched one by one (the rest share one launch); from the last nbody_octree_info
+  int ncu = 0;                         // compute units of the device (the all-level kernels launch at most one block per CU)
   uint32_t step_budget = 0;            // nbody_octree_set_step_budget: visit rounds a body may make; 0 = the node pool size
   uint32_t n = 0, capacity = 0, max_cells = 0, bounds_blocks = 0;
   size_t tsz = 0;
@@ -1212,14 +1308,30 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
                      static_cast<const T*>(s->x), tree, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
-  uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
-  for (int l = 0; l < kMaxLevels<D>; ++l) {
-    const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
-    hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l * NCH + kOBuild - 1) / kOBuild)), dim3(kOBuild), 0, st, l,
-                       t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->cells,
-                       t->lvl_count, flags, t->capacity, t->max_cells);
+  // Levels [0, own) get a launch each; the levels behind them — empty unless the tree has grown deeper than the last
+  // nbody_octree_info saw it (+ 2) — share ONE launch that walks them with a grid barrier and normally returns at once.  (All levels
+  // behind grid barriers, nbody_octree_set_build(t, 2), is slower on this chip: an agent-scope barrier has to write back and
+  // invalidate the per-XCD L2s and costs ~12 us, a dependent launch 4.6 us — N = 10^5: 0.87 against 0.55 ms per step.)
+  const int own = t->build == 2 ? 0 : (t->depth_hint < kMaxLevels<D> ? t->depth_hint : kMaxLevels<D>);
+  {
+    uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
+    for (int l = 0; l < own; ++l) {
+      const uint64_t cap_l = width < uint64_t(n / 2 + 1) ? width : uint64_t(n / 2 + 1);
+      hipLaunchKernelGGL((ot_build_level_kernel<T, D>), dim3(uint32_t((cap_l * NCH + kOBuild - 1) / kOBuild)), dim3(kOBuild), 0, st, l,
+                         t->keys[fin], t->idx[fin], static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->cells,
+                         t->lvl_count, flags, t->capacity, t->max_cells);
+      NB_HIP(hipGetLastError());
+      if (width < (uint64_t(1) << 40)) width *= NCH;
+    }
+  }
+  if (own < kMaxLevels<D>) {  // at most one block per CU, and no more blocks than the widest level can use
+    const uint64_t widest = uint64_t(n / 2 + 1) * NCH;
+    uint32_t grid         = uint32_t((widest + kOBuild - 1) / kOBuild);
+    if (grid > uint32_t(t->ncu)) grid = uint32_t(t->ncu);
+    hipLaunchKernelGGL((ot_build_all_levels_kernel<T, D>), dim3(grid), dim3(kOBuild), 0, st, t->keys[fin], t->idx[fin],
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->cells, t->lvl_count, flags, t->capacity,
+                       t->max_cells, own);
     NB_HIP(hipGetLastError());
-    if (width < (uint64_t(1) << 40)) width *= NCH;
   }
   // cells still holding >= 2 bodies at the key depth (none in a typical step: the kernel then returns at once)
   hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
@@ -1233,7 +1345,15 @@ template <typename T, int D>
 static int ot_tree_run(nbody_octree* t, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
   const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
-  for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
+  const int own = t->build == 2 ? 0 : (t->depth_hint < kMaxLevels<D> ? t->depth_hint : kMaxLevels<D>);
+  if (own < kMaxLevels<D>) {  // the levels below `own`, deepest first, in one launch (see ot_insert_run)
+    uint32_t grid = (t->n / 2 + 1 + kOB - 1) / kOB;
+    if (grid > uint32_t(t->ncu)) grid = uint32_t(t->ncu);
+    hipLaunchKernelGGL((ot_multipole_all_levels_kernel<T, D>), dim3(grid), dim3(kOB), 0, st, tree, t->cells, t->lvl_count,
+                       t->lvl_count + (kMaxLevels<D> + 4), t->lvl_count + (kMaxLevels<D> + 2), own);
+    NB_HIP(hipGetLastError());
+  }
+  for (int l = own - 1; l >= 0; --l) {
     uint64_t width = 1;
     for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
     const uint64_t cap_l = width < uint64_t(t->n / 2 + 1) ? width : uint64_t(t->n / 2 + 1);
@@ -1311,6 +1431,14 @@ extern "C" int nbody_octree_set_walk(nbody_octree* t, int mode) {
   return NBODY_OK;
 }
 
+extern "C" int nbody_octree_set_build(nbody_octree* t, int mode) {
+  NB_ARG(t != nullptr, "nbody_octree is NULL");
+  NB_ARG(mode >= 0 && mode <= 2, "build form must be 0 (auto), 1 (one launch per level) or 2 (all levels in one launch), got %d", mode);
+  t->build = mode;
+  if (mode == 1) t->depth_hint = 64;  // every level its own launch, whatever earlier trees looked like
+  return NBODY_OK;
+}
+
 extern "C" int nbody_octree_set_step_budget(nbody_octree* t, uint32_t steps) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
   t->step_budget = steps;
@@ -1363,9 +1491,14 @@ extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, ui
                                       : (dim == 3 ? sizeof(ot_group<double, 3>) : sizeof(ot_group<double, 2>));
   NB_ALLOC(t->groups, t->group_bytes * size_t(t->max_cells));
   NB_ALLOC(t->cells, sizeof(ot_cell) * size_t(t->max_cells));
-  NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 3));
+  NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 5));  // level counts, deep groups, flags, two grid-barrier counters
 #undef NB_ALLOC
-  if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 3)); e != hipSuccess) return fail(e, "hipMemset");
+  if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 5)); e != hipSuccess) return fail(e, "hipMemset");
+  {
+    hipDeviceProp_t prop;
+    if (hipError_t e = hipGetDeviceProperties(&prop, device); e != hipSuccess) return fail(e, "hipGetDeviceProperties");
+    t->ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 1;
+  }
   *out = t;
   return NBODY_OK;
 }
@@ -1483,6 +1616,11 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
     set_error("octree node pool exhausted (capacity %u nodes = System::max_tree_node_size)", t->capacity);
     return NBODY_ERR_STATE;
   }
+  if (flags & kFlagBarrier) {
+    set_error("octree build: a grid barrier of the all-level kernels timed out (the blocks of one launch were not all running "
+              "within seconds: is the GPU shared?); nbody_octree_set_build(t, 1) builds with one launch per level");
+    return NBODY_ERR_STATE;
+  }
   if (flags & kFlagStack) {
     set_error("octree walk: more pending nodes than the per-body stack holds (a tree far deeper than %d levels)", maxl);
     return NBODY_ERR_STATE;
@@ -1492,6 +1630,10 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
               t->step_budget ? "the budget set with nbody_octree_set_step_budget" : "more than the tree has nodes: the tree is damaged");
     return NBODY_ERR_STATE;
   }
+  int deepest = -1;
+  for (int l = 0; l < maxl; ++l)
+    if (lv[l] != 0) deepest = l;
+  t->depth_hint = deepest + 3 < maxl ? deepest + 3 : maxl;  // the levels the next builds launch one by one: what this tree used + 2
   uint64_t cells = 0;
   for (int l = 0; l <= maxl + 1; ++l) cells += lv[l];  // breadth-first levels, then the groups of the deep build
   if (tree_size) *tree_size = uint32_t(1 + cells * (1u << t->dim));  // next_free_child_group (src/octree.h:152)

@@ -56,6 +56,9 @@ static __global__ __launch_bounds__(kSortB) void radix_scan_rows_kernel(uint32_t
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// FUSED: the per-digit row scan over the blocks is done here, by every block for itself (thread d adds row d of the histogram up
+// to its own block and to the end) — one launch less per pass.  For few blocks only (the rows are read once per block).
+template <bool FUSED>
 static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ hist,
@@ -91,8 +94,23 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
     if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
     __builtin_amdgcn_wave_barrier();
   }
+  __shared__ uint32_t dtot[256];   // FUSED: the digit totals this block computed itself
+  uint32_t before_me = 0;          // FUSED: keys with this digit in the blocks before this one
   {  // digit = threadIdx.x: exclusive scan of totals[0..255]; within a wave here, wave offsets after the barrier
-    const uint32_t v = totals[threadIdx.x];
+    uint32_t v;
+    if constexpr (FUSED) {
+      const uint32_t* row = hist + uint64_t(threadIdx.x) * nblk;
+      uint32_t tot = 0;
+      for (uint32_t b = 0; b < nblk; ++b) {
+        const uint32_t h = row[b];
+        before_me += b < blockIdx.x ? h : 0u;
+        tot += h;
+      }
+      dtot[threadIdx.x] = tot;
+      v                 = tot;
+    } else {
+      v = totals[threadIdx.x];
+    }
     uint32_t inc     = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -105,8 +123,9 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
   // digit = threadIdx.x: turn per-wave counts into global bases
   {
     uint32_t woff = 0;
-    for (int w = 0; w < wave; ++w) woff += dbase[w * 64 + 63] + totals[w * 64 + 63];  // totals of the earlier 64-digit groups
-    uint32_t run = woff + dbase[threadIdx.x] + hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
+    for (int w = 0; w < wave; ++w)  // totals of the earlier 64-digit groups
+      woff += dbase[w * 64 + 63] + (FUSED ? dtot[w * 64 + 63] : totals[w * 64 + 63]);
+    uint32_t run = woff + dbase[threadIdx.x] + (FUSED ? before_me : hist[uint64_t(threadIdx.x) * nblk + blockIdx.x]);
 #pragma unroll
     for (int w = 0; w < kSortB / 64; ++w) {
       uint32_t cw          = wcnt[w][threadIdx.x];
@@ -131,6 +150,9 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
 // hist needs 256 * (nblk + 1) u32, nblk = radix_sort_blocks(n).  Sorts by key bits [0, key_bits): the pairs start in
 // (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.
 inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+// Measured (profiles/r03/small_trees_kernel_stats.txt): at 49 blocks (N = 10^5) the fused scatter takes 13.2 us against 8 + 5 for
+// scatter + scan — nothing gained; at 5 blocks (N = 10^4) the octree step goes from 0.324 to 0.278 ms.
+constexpr uint32_t kSortFusedBlocks = 16;  // up to 32 768 keys: every block scans the 256 x nblk histogram itself
 
 inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int key_bits, uint32_t* hist, hipStream_t st,
                             int* final_buf) {
@@ -140,11 +162,17 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
   for (int shift = 0; shift < key_bits; shift += 8) {
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], n, shift, hist, nblk);
     NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kSortB), 0, st, hist, nblk, hist + 256u * size_t(nblk));
-    NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1], idx[cur ^ 1], n,
-                       shift, hist, hist + 256u * size_t(nblk), nblk);
-    NB_HIP(hipGetLastError());
+    if (nblk <= kSortFusedBlocks) {  // small sorts are bound by their dependent launches: 2 per pass instead of 3
+      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1], idx[cur ^ 1],
+                         n, shift, hist, hist + 256u * size_t(nblk), nblk);
+      NB_HIP(hipGetLastError());
+    } else {
+      hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kSortB), 0, st, hist, nblk, hist + 256u * size_t(nblk));
+      NB_HIP(hipGetLastError());
+      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1],
+                         idx[cur ^ 1], n, shift, hist, hist + 256u * size_t(nblk), nblk);
+      NB_HIP(hipGetLastError());
+    }
     cur ^= 1;
     idx_in = idx[cur];
   }

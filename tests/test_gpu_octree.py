@@ -449,3 +449,50 @@ def test_octree_walk_stack_full_and_step_budget_exits(nb, oracle, form):
     assert np.all(np.isfinite(a5))
     afull, _, err = _walk_with_canaries(nb, gal, 0.5, form)
     assert err is None and not np.array_equal(a5, afull)
+
+
+@pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2), (0, 2)])
+def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
+    """Three ways to launch the breadth-first build and the multipole pass: one launch per level (1); auto (0): one launch per
+    level the previous tree used (+ 2) and ONE launch that walks all deeper levels behind a grid barrier — the second build of
+    each case below runs with the depth the first one reported; every level behind the grid barrier (2).  Same tree size, same
+    root monopole, same per-body counters and accelerations, bit for bit — also with cells below the key depth, with a 60-level
+    chain of nested cells (the deeper levels are NOT empty for a hint taken from a shallow tree), and for two bodies."""
+    cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2)]
+    if dim == 3:
+        cases.append(("plummer", 5000))
+    for wl, n in cases:
+        res = []
+        for form in (2, 1, 0):
+            hs = nb.build_model(dtype, dim, wl, n)
+            if wl == "uniform":  # pairs far below the key resolution and an escaper that inflates the root cube
+                hs.x[1] = hs.x[0] + (1e-9 if dtype == 1 else 1e-6)
+                hs.x[5] = 4e3
+            dev = nb.DeviceSystem.from_host(hs)
+            dev.octree.set_build(form)
+            dev.octree.enable_counters(True)
+            for _ in range(2):   # twice: the barrier counters are reset by every build; auto then knows the depth
+                dev.octree_force(0.5)
+                dev.sync()
+                size, mass = dev.octree.info(dev.stream)
+            res.append((size, mass, dev.octree.read_counters(dev.stream).copy(), dev.download().a.copy()))
+            dev.close()
+        for r in res[1:]:
+            assert res[0][0] == r[0] and res[0][1] == r[1], (wl, n)
+            assert np.array_equal(res[0][2], r[2]) and np.array_equal(res[0][3], r[3]), (wl, n)
+    if dtype == 1 and dim == 3:
+        outs = []
+        for form in (2, 1, 0):
+            # auto: the hint comes from a shallow tree first (a galaxy of as many bodies), then the chain is built with it
+            shallow = nb.build_model(1, 3, "galaxy", _deep_chain(nb, 60).n)
+            dev = nb.DeviceSystem.from_host(shallow)
+            dev.octree.set_build(form)
+            dev.octree_force(0.5)
+            dev.octree.info(dev.stream)
+            dev.upload(_deep_chain(nb, 60))
+            dev.octree_force(0.0)
+            dev.sync()
+            outs.append((dev.octree.info(dev.stream), dev.download().a.copy()))
+            dev.close()
+        for o in outs[1:]:
+            assert outs[0][0] == o[0] and np.array_equal(outs[0][1], o[1])

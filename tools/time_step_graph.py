@@ -1,0 +1,40 @@
+"""Diagnostic: ms per whole step of the tree algorithms when the step is recorded once and replayed (what the CLI's default and
+--csv-total modes do), galaxy, theta 0.5 — the octree with its levels as one launch each against all levels in one launch.
+    python tools/time_step_graph.py [float]"""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+from conftest import load_package
+nb = load_package()
+dtype = nb.F32 if (len(sys.argv) > 1 and sys.argv[1] == "float") else nb.F64
+
+
+def per_step(dev, step, steps=200):
+    step(); dev.sync()                    # everything allocated before the capture
+    g = nb.StepGraph(dev, step)
+    for _ in range(10):
+        g.launch()
+    dev.sync()
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.launch()
+        dev.sync()
+        best = min(best, (time.perf_counter() - t0) / steps * 1e3)
+    g.close()
+    return best
+
+
+for n in (10000, 100000, 1000000):
+    row = []
+    for form in (1, 0, 2):
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+        dev.octree.set_build(form)
+        dev.octree_force(0.5); dev.octree.info(dev.stream)   # auto: the tree's depth is known from here on
+        row.append("octree build=%d %.3f" % (form, per_step(dev, lambda: (dev.octree_force(0.5), dev.accelerate_step()), 200 if n < 1000000 else 50)))
+        dev.octree.info(dev.stream)
+        dev.close()
+    dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+    row.append("bvh %.3f" % per_step(dev, lambda: (dev.bvh_force(0.5), dev.accelerate_step()), 200 if n < 1000000 else 50))
+    dev.close()
+    print("n=%d dtype=%d ms/step (graph replay): " % (n, dtype) + "  ".join(row), flush=True)

@@ -1242,6 +1242,260 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   }
 }
 
+
+// ---- the same visit round for single precision in 3D (the reference's DEFAULT run: float, octree) ------------------------------
+// 192-byte sibling groups: (p0, p1, p2, m) x 8 | (fc, depth) x 8 — two loads per round.  Same tests, same arithmetic in the same
+// order as ot_force_kernel<float, 3>: the quick test q = side * rsq(d2), ql = q - q (eps y) against theta (1 -+ 2^-16); if a
+// non-leaf lane is inside the band the wave evaluates the reference's side / (sqrt(d2) + eps) < theta with the correctly rounded
+// f32 square root and quotient (v_sqrt_f32 / v_rcp_f32 seeds + the fix-up sequences hipcc emits for them, instruction for
+// instruction); the accepted term m y^3 (1 - 3 eps y), the guarded form below d2 = 2^-18 per lane.  The record lives in v[54:57]
+// and v[62:63], temporaries in v52, v53, v58-v61.
+#define OT_FAR_F32                                                                                                        \
+  "v_mul_f32_e32 %[t], %[y], %[y]\n\t"                                                                                    \
+  "v_mul_f32_e32 %[t], %[y], %[t]\n\t"                                                                                    \
+  "v_mul_f32_e32 %[w], v57, %[t]\n\t"                                                                                     \
+  "v_mul_f32_e32 %[t], %[m3eps], %[y]\n\t"                                                                                \
+  "v_fmac_f32_e32 %[w], %[w], %[t]\n\t"
+
+#define OT_ISA_TEXT_F32(CNT_N, CNT_T)                                                                                     \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  "v_cmp_ne_u32_e32 vcc, 0, %[more]\n\t"                                                                                  \
+  "s_and_b64 exec, exec, vcc\n\t"                                                                                         \
+  "s_cbranch_execz .LOFend%=\n"                                                                                           \
+  ".LOFtop%=:\n\t"                                                                                                        \
+  "v_mad_u32_u24 %[oa], %[cur], %[s192], %[cc16]\n\t"                                                                     \
+  "v_mad_u32_u24 %[of], %[cur], %[s192], %[cc8]\n\t"                                                                      \
+  "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
+  "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"                                                                    \
+  CNT_N                                                                                                                   \
+  "s_waitcnt vmcnt(1)\n\t"                                                                                                \
+  "v_sub_f32_e32 %[d0], v54, %[xi0]\n\t"                                                                                  \
+  "v_sub_f32_e32 %[d1], v55, %[xi1]\n\t"                                                                                  \
+  "v_sub_f32_e32 %[d2], v56, %[xi2]\n\t"                                                                                  \
+  "v_fma_f32 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
+  "v_fmac_f32_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
+  "v_fmac_f32_e32 %[r2], %[d2], %[d2]\n\t"                                                                                \
+  "v_rsq_f32_e32 %[y], %[r2]\n\t"                                                                                         \
+  "s_waitcnt vmcnt(0)\n\t"                                                                                                \
+  "v_sub_u32_e32 %[t], 0, v63\n\t"                                                                                        \
+  "v_ldexp_f32 %[g], %[rootside], %[t]\n\t"                                                                               \
+  "v_cmp_gt_u32_e64 %[nonleaf], -2, v62\n\t"                                                                              \
+  "v_mul_f32_e32 %[w], %[g], %[y]\n\t"                                                                                    \
+  "v_mul_f32_e32 %[t], %[meps], %[y]\n\t"                                                                                 \
+  "v_cmp_lt_f32_e64 %[st], %[w], %[lo]\n\t"                                                                               \
+  "v_fmac_f32_e32 %[w], %[w], %[t]\n\t"                                                                                   \
+  "v_cmp_gt_f32_e64 %[so], %[w], %[hi]\n\t"                                                                               \
+  "s_or_b64 %[so], %[so], %[st]\n\t"                                                                                      \
+  "s_andn2_b64 %[so], %[nonleaf], %[so]\n\t"                                                                              \
+  "s_cbranch_scc1 .LOFexact%=\n"                                                                                          \
+  ".LOFdecided%=:\n\t"                                                                                                    \
+  "s_andn2_b64 %[take], exec, %[nonleaf]\n\t"                                                                             \
+  "s_or_b64 %[take], %[take], %[st]\n\t"                                                                                  \
+  "s_mov_b64 %[act], exec\n\t"                                                                                            \
+  "s_andn2_b64 %[open], exec, %[take]\n\t"                                                                                \
+  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
+  "s_cbranch_scc0 .LOFnotake%=\n\t"                                                                                       \
+  OT_FAR_F32                                                                                                              \
+  "v_cmp_gt_u32_e64 %[near], %[nearbits], %[r2]\n\t"                                                                      \
+  CNT_T                                                                                                                   \
+  "s_cmp_lg_u64 %[near], 0\n\t"                                                                                           \
+  "s_cbranch_scc1 .LOFnear%=\n"                                                                                           \
+  ".LOFacc%=:\n\t"                                                                                                        \
+  "v_fmac_f32_e32 %[acc0], %[w], %[d0]\n\t"                                                                               \
+  "v_fmac_f32_e32 %[acc1], %[w], %[d1]\n\t"                                                                               \
+  "v_fmac_f32_e32 %[acc2], %[w], %[d2]\n"                                                                                 \
+  ".LOFnotake%=:\n\t"                                                                                                     \
+  "s_mov_b64 exec, %[act]\n\t"                                                                                            \
+  "v_lshrrev_b64 v[52:53], %[gshift], %[open]\n\t"                                                                        \
+  "v_and_b32_e32 v52, 0xff, v52\n\t"                                                                                      \
+  "v_bcnt_u32_b32 %[nsp], v52, %[sp]\n\t"                                                                                 \
+  "s_and_b64 exec, %[open], %[open]\n\t"                                                                                  \
+  "v_lshrrev_b32_e32 v53, %[ccp1], v52\n\t"                                                                               \
+  "v_bcnt_u32_b32 v53, v53, %[sp]\n\t"                                                                                    \
+  "v_lshl_add_u32 v53, v53, 5, %[stk]\n\t"                                                                                \
+  "ds_write_b32 v53, v62\n\t"                                                                                             \
+  "s_mov_b64 exec, %[act]\n\t"                                                                                            \
+  "v_add_u32_e32 %[sp], -1, %[nsp]\n\t"                                                                                   \
+  "v_cmpx_gt_u32_e64 %[act], %[depth], %[sp]\n\t"                                                                         \
+  "s_cbranch_execz .LOFend%=\n\t"                                                                                         \
+  "v_lshl_add_u32 v53, %[sp], 5, %[stk]\n\t"                                                                              \
+  "ds_read_b32 %[cur], v53\n\t"                                                                                           \
+  "s_add_i32 %[guard], %[guard], -1\n\t"                                                                                  \
+  "s_cmp_lg_u32 %[guard], 0\n\t"                                                                                          \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
+  "s_cbranch_scc1 .LOFtop%=\n\t"                                                                                          \
+  "s_mov_b32 %[gflag], 1\n\t"                                                                                             \
+  "s_branch .LOFend%=\n"                                                                                                  \
+  ".LOFexact%=:\n\t" /* the reference's expression with correctly rounded sqrt and quotient, for every lane (ot_accept) */  \
+  "v_mul_f32_e32 v52, %[d0], %[d0]\n\t"                                                                                   \
+  "v_mul_f32_e32 v53, %[d1], %[d1]\n\t"                                                                                   \
+  "v_add_f32_e32 v52, v52, v53\n\t"                                                                                       \
+  "v_mul_f32_e32 v53, %[d2], %[d2]\n\t"                                                                                   \
+  "v_add_f32_e32 v52, v53, v52\n\t"                                                                                       \
+  "v_mul_f32_e32 v53, 0x4f800000, v52\n\t"                                                                                \
+  "v_cmp_gt_f32_e32 vcc, %[sqmin], v52\n\t"                                                                               \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_cndmask_b32_e32 v52, v52, v53, vcc\n\t"                                                                              \
+  "v_sqrt_f32_e32 v53, v52\n\t"                                                                                           \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_add_u32_e32 v58, -1, v53\n\t"                                                                                        \
+  "v_fma_f32 v59, -v58, v53, v52\n\t"                                                                                     \
+  "v_cmp_ge_f32_e64 %[so2], 0, v59\n\t"                                                                                   \
+  "v_add_u32_e32 v59, 1, v53\n\t"                                                                                         \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_cndmask_b32_e64 v58, v53, v58, %[so2]\n\t"                                                                           \
+  "v_fma_f32 v53, -v59, v53, v52\n\t"                                                                                     \
+  "v_cmp_lt_f32_e64 %[so2], 0, v53\n\t"                                                                                   \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_cndmask_b32_e64 v53, v58, v59, %[so2]\n\t"                                                                           \
+  "v_mul_f32_e32 v58, 0x37800000, v53\n\t"                                                                                \
+  "v_cndmask_b32_e32 v53, v53, v58, vcc\n\t"                                                                              \
+  "v_mov_b32_e32 v58, 0x260\n\t"                                                                                          \
+  "v_cmp_class_f32_e32 vcc, v52, v58\n\t"                                                                                 \
+  "s_nop 1\n\t"                                                                                                           \
+  "v_cndmask_b32_e32 v52, v53, v52, vcc\n\t"                                                                              \
+  "v_add_f32_e32 v52, %[eps], v52\n\t"                                                                                    \
+  "v_div_scale_f32 v53, %[so2], v52, v52, %[g]\n\t"                                                                       \
+  "v_rcp_f32_e32 v58, v53\n\t"                                                                                            \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_fma_f32 v59, -v53, v58, 1.0\n\t"                                                                                     \
+  "v_fmac_f32_e32 v58, v59, v58\n\t"                                                                                      \
+  "v_div_scale_f32 v59, vcc, %[g], v52, %[g]\n\t"                                                                         \
+  "v_mul_f32_e32 v60, v59, v58\n\t"                                                                                       \
+  "v_fma_f32 v61, -v53, v60, v59\n\t"                                                                                     \
+  "v_fmac_f32_e32 v60, v61, v58\n\t"                                                                                      \
+  "v_fma_f32 v53, -v53, v60, v59\n\t"                                                                                     \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_div_fmas_f32 v53, v53, v58, v60\n\t"                                                                                 \
+  "v_div_fixup_f32 v52, v53, v52, %[g]\n\t"                                                                               \
+  "v_cmp_gt_f32_e64 %[st], %[theta], v52\n\t"                                                                             \
+  "s_branch .LOFdecided%=\n"                                                                                              \
+  ".LOFnear%=:\n\t" /* an accepted child closer than 2^-9 (the body's own leaf, coincident bodies): the guarded form, per lane */\
+  "s_mov_b64 %[so], exec\n\t"                                                                                             \
+  "s_mov_b64 exec, %[near]\n\t"                                                                                           \
+  "v_mul_f32_e32 %[t], %[r2], %[y]\n\t"                                                                                   \
+  "v_fma_f32 v52, -%[t], %[y], 1.0\n\t"                                                                                   \
+  "v_mul_f32_e32 v53, 0.5, %[t]\n\t"                                                                                      \
+  "v_fmac_f32_e32 %[t], v53, v52\n\t"                                                                                     \
+  "v_add_f32_e32 %[t], %[eps], %[t]\n\t"                                                                                  \
+  "v_mul_f32_e32 v52, %[t], %[t]\n\t"                                                                                     \
+  "v_mul_f32_e32 %[t], %[t], v52\n\t"                                                                                     \
+  "v_rcp_f32_e32 v52, %[t]\n\t"                                                                                           \
+  "s_nop 0\n\t"                                                                                                           \
+  "v_fma_f32 %[t], -%[t], v52, 1.0\n\t"                                                                                   \
+  "v_fmac_f32_e32 v52, v52, %[t]\n\t"                                                                                     \
+  "v_mul_f32_e32 %[w], v57, v52\n\t"                                                                                      \
+  "s_mov_b64 exec, %[so]\n\t"                                                                                             \
+  "s_branch .LOFacc%=\n"                                                                                                  \
+  ".LOFend%=:\n\t"                                                                                                        \
+  "s_mov_b64 exec, %[sv]"
+
+__device__ __forceinline__ float ot_to_sgpr(float v) {
+  uint32_t r;
+  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(__builtin_bit_cast(uint32_t, v)));
+  return __builtin_bit_cast(float, r);
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<float>* __restrict__ rootrec,
+                                                              const ot_group<float, 3>* __restrict__ groups,
+                                                              const uint32_t* __restrict__ list, uint32_t nlist,
+                                                              const float* __restrict__ x, float* __restrict__ a, float c,
+                                                              uint32_t first, float theta, uint32_t capacity,
+                                                              const float* __restrict__ root, uint32_t* __restrict__ flags,
+                                                              uint32_t* __restrict__ counters) {
+  using T = float;
+  constexpr int D = 3;
+  constexpr uint32_t NCH = 8, GPW = 8;
+  constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;
+  static_assert(sizeof(ot_group<float, 3>) == 192, "the round addresses 192-byte sibling groups");
+  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * 8 + g) * 4
+  const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
+  const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
+  const bool valid    = t < nlist;
+  const uint32_t body = valid ? list[t] : first;
+  const ot_theta<T> th(theta);
+  const pair_consts<T> pc;
+  const T root_side = root[D];
+  T xi[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
+    acc[k] = T(0);
+  }
+  uint32_t c_nodes = 0, c_terms = 0;
+  uint32_t cur = 0;
+  bool more = false;
+  if (valid) {  // the root is examined alone, exactly as in ot_force_kernel
+    const ot_node<T> nd = *rootrec;
+    T di[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
+    const T d2f     = ot_dist2_fused<T, D>(di);
+    const T y0      = ot_rsq(d2f);
+    const bool leaf = nd.fc >= kOtBody;
+    const bool take = leaf || ot_accept<T, D>(!leaf, root_side, di, y0, th);
+    {
+      const bool on0    = take && cc == 0;
+      const uint64_t m0 = __builtin_amdgcn_ballot_w64(on0);
+      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, acc, di, nd.m, d2f, y0, pc);
+    }
+    if (COUNT && cc == 0) {
+      c_nodes = 1;
+      c_terms = take;
+    }
+    more = !take;
+    cur  = nd.fc;
+  }
+  uint32_t more_v = more ? 1u : 0u, sp = 0, nsp = 0, gflag = 0, guard = capacity;
+  const uint32_t cc16 = cc * 16u, cc8 = 128u + cc * 8u, gshift = threadIdx.x & 56u, ccp1 = cc + 1u;
+  const uint32_t stk = uint32_t(reinterpret_cast<uintptr_t>(&stack[0][g]));
+  float lo = ot_to_sgpr(th.lo), hi = ot_to_sgpr(th.hi), thx = ot_to_sgpr(th.exact), tiny = ot_consts<T>::tiny, eps = ot_consts<T>::eps,
+        meps = -ot_consts<T>::eps, m3eps = -(3.0f * ot_consts<T>::eps), sqmin = 0x1p-96f, rs = ot_to_sgpr(root_side);
+  uint32_t nearbits = ot_near<T>::bits, s192 = 192u, depth = DEPTH;
+  asm volatile("" : "+s"(tiny), "+s"(eps), "+s"(meps), "+s"(m3eps), "+s"(sqmin), "+s"(nearbits), "+s"(s192), "+s"(depth));
+  float d0, d1, d2, r2, y, gq, w, tt;
+  uint32_t oa, of;
+  uint64_t nonleaf, st, so, so2, take, open, act, sv, near;
+#define OT_OPERANDS                                                                                                        \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [cur] "+v"(cur), [sp] "+v"(sp), [nsp] "+v"(nsp),          \
+    OT_CNT_OPERANDS [guard] "+s"(guard), [gflag] "+s"(gflag), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2),              \
+    [r2] "=&v"(r2), [y] "=&v"(y), [g] "=&v"(gq), [w] "=&v"(w), [t] "=&v"(tt), [oa] "=&v"(oa), [of] "=&v"(of),             \
+    [nonleaf] "=&s"(nonleaf), [st] "=&s"(st), [so] "=&s"(so), [so2] "=&s"(so2), [take] "=&s"(take), [open] "=&s"(open),     \
+    [act] "=&s"(act), [sv] "=&s"(sv), [near] "=&s"(near)                                                                   \
+  : [more] "v"(more_v), [groups] "s"(groups), [xi0] "v"(xi[0]), [xi1] "v"(xi[1]), [xi2] "v"(xi[2]), [cc16] "v"(cc16),     \
+    [cc8] "v"(cc8), [gshift] "v"(gshift), [ccp1] "v"(ccp1), [stk] "v"(stk), [lo] "s"(lo), [hi] "s"(hi), [theta] "s"(thx),  \
+    [tiny] "s"(tiny), [eps] "s"(eps), [meps] "s"(meps), [m3eps] "s"(m3eps), [sqmin] "s"(sqmin), [nearbits] "s"(nearbits),  \
+    [rootside] "s"(rs), [s192] "s"(s192), [depth] "s"(depth)                                                              \
+  : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
+#define OT_CNT_OPERANDS [cn] "+v"(c_nodes), [ct] "+v"(c_terms),
+  if constexpr (COUNT) asm volatile(OT_ISA_TEXT_F32("v_add_u32_e32 %[cn], 1, %[cn]\n\t", "v_add_u32_e32 %[ct], 1, %[ct]\n\t") OT_OPERANDS);
+#undef OT_CNT_OPERANDS
+#define OT_CNT_OPERANDS
+  if constexpr (!COUNT) asm volatile(OT_ISA_TEXT_F32("", "") OT_OPERANDS);
+#undef OT_CNT_OPERANDS
+#undef OT_OPERANDS
+  if (more && nsp > DEPTH && cc == 0) atomicOr(flags, kFlagStack);
+  if (gflag != 0u && threadIdx.x == 0) atomicOr(flags, kFlagWalk);
+#pragma unroll
+  for (uint32_t off = NCH / 2; off > 0; off >>= 1) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] += __shfl_xor(acc[k], int(off), 64);
+    if (COUNT) {
+      c_nodes += __shfl_xor(c_nodes, int(off), 64);
+      c_terms += __shfl_xor(c_terms, int(off), 64);
+    }
+  }
+  if (valid && cc == 0) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(body - first) * D + k] = c * acc[k];
+    if (COUNT) {
+      counters[uint64_t(body) * 2 + 0] = c_nodes;
+      counters[uint64_t(body) * 2 + 1] = c_terms;
+    }
+  }
+}
+
 }  // namespace nbody
 
 // ---- host side / C ABI -----------------------------------------------------------------------------------------------
@@ -1389,26 +1643,32 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
                      static_cast<T>(theta), budget, static_cast<const T*>(t->root),                                        \
                      t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
-  // double, 3D: the visit round written as ISA (ot_force_isa_kernel), while 32-bit group offsets reach the whole array;
-  // nbody_octree_set_walk(t, 1) keeps the compiler-scheduled kernel (tests compare the two bitwise)
+  // 3D: the visit round written as ISA (ot_force_isa_kernel, ot_force_isa_f32_kernel), while 24-bit group numbers times the group
+  // size stay inside 32-bit offsets; nbody_octree_set_walk(t, 1) keeps the compiler-scheduled kernel (tests compare the two bitwise)
   bool isa = false;
-  if constexpr (sizeof(T) == 8 && D == 3) {
+  if constexpr (D == 3) {
     const char* fe = experiment_env("NBODY_OT_FORM");  // -DNBODY_EXPERIMENTS builds only
-    isa            = t->walk != 1 && !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32);
+    isa = t->walk != 1 && !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32) &&
+          t->max_cells < (1u << 24);
   }
   if (t->walk == 2 && !isa) {
-    set_error("octree walk: the ISA visit round exists for double 3D (and trees within 32-bit group offsets) only");
+    set_error("octree walk: the ISA visit round exists in 3D (and for trees within 32-bit group offsets) only");
     return NBODY_ERR_ARG;
   }
   if (isa) {
-    if constexpr (sizeof(T) == 8 && D == 3) {
-#define NB_OT_ISA(CNT)                                                                                                       \
-  hipLaunchKernelGGL((ot_force_isa_kernel<CNT>), dim3(blocks), dim3(64), 0, st, rootrec,                                     \
-                     static_cast<const ot_group<T, D>*>(t->groups), list, s->count, static_cast<const T*>(s->x),            \
-                     static_cast<T*>(s->a), static_cast<T>(s->c), s->first, static_cast<T>(theta), budget,                  \
-                     static_cast<const T*>(t->root), t->lvl_count + (kMaxLevels<3> + 2), t->counters)
-      if (t->counters_on) NB_OT_ISA(true);
-      else NB_OT_ISA(false);
+    if constexpr (D == 3) {
+#define NB_OT_ISA(KERN, CNT)                                                                                                 \
+  hipLaunchKernelGGL((KERN<CNT>), dim3(blocks), dim3(64), 0, st, rootrec, static_cast<const ot_group<T, D>*>(t->groups), list, \
+                     s->count, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,           \
+                     static_cast<T>(theta), budget, static_cast<const T*>(t->root), t->lvl_count + (kMaxLevels<3> + 2),      \
+                     t->counters)
+      if constexpr (sizeof(T) == 8) {
+        if (t->counters_on) NB_OT_ISA(ot_force_isa_kernel, true);
+        else NB_OT_ISA(ot_force_isa_kernel, false);
+      } else {
+        if (t->counters_on) NB_OT_ISA(ot_force_isa_f32_kernel, true);
+        else NB_OT_ISA(ot_force_isa_f32_kernel, false);
+      }
 #undef NB_OT_ISA
     }
   } else if (t->counters_on) NB_OT_LAUNCH(true);

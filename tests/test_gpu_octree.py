@@ -58,19 +58,22 @@ def test_octree_force_is_deterministic(nb):
     assert np.array_equal(runs[0], runs[1])
 
 
-def test_octree_walk_forms_are_bitwise_equal(nb):
-    """The visit round written as ISA (double, 3D: what runs by default) and the compiler-scheduled kernel
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_octree_walk_forms_are_bitwise_equal(nb, dtype):
+    """The visit round written as ISA (3D, double and float — float octree is the reference's DEFAULT run, src/arguments.h:23-30:
+    what runs by default) and the compiler-scheduled kernel
     (nbody_octree_set_walk: 2 / 1) perform the same tests and the same arithmetic in the same order: accelerations and counters equal
     bit for bit — fresh and clustered systems, theta 0 (every node opened: the deepest stacks), a shard window."""
     import os
     rng = np.random.default_rng(7)
-    cases = [("galaxy", 50000, 0.5), ("uniform", 20011, 0.0), ("galaxy", 4096, 1.2), ("plummer", 30000, 0.3)]
+    cases = [("galaxy", 50000, 0.5), ("uniform", 20011, 0.0), ("galaxy", 4096, 1.2), ("plummer", 30000, 0.3), ("uniform", 60000, 0.7),
+             ("galaxy", 300000, 0.5)]   # theta 0.7 on a dense cube: many lanes inside the guard band of the quick test
     for wl, n, theta in cases:
         res = []
         for form in (2, 1):
-            hs = nb.build_model(1, 3, wl, n)
+            hs = nb.build_model(dtype, 3, wl, n)
             if wl == "uniform":  # tight pairs and a far escaper: near-pair path, cells below the usual depth
-                hs.x[1] = hs.x[0] + 1e-9
+                hs.x[1] = hs.x[0] + (1e-9 if dtype == 1 else 1e-5)
                 hs.x[3] = 1e3
             dev = nb.DeviceSystem.from_host(hs)
             dev.octree.set_walk(form)

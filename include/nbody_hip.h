@@ -156,7 +156,8 @@ int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* s
 int nbody_bvh_enable_counters(nbody_bvh* t, int on);
 /* K9 scheduling form: 0 = auto, 1 = one independent stackless walk per lane (the reference's loop as is),
  * 2 = wave-cooperative sweep of the union of the wave's walks in DFS key order (3 / 4: the compiler-scheduled step
- * program with 1 / 2 bodies per lane; 5: the step program written out as ISA — what 0 and 2 use).  All forms make
+ * program with 1 / 2 bodies per lane; 5: the step program written out as ISA — what 0 and 2 use; 6: four independent
+ * 16-lane row sweeps per wave, a measured experiment without counters).  All forms make
  * every body perform the same tests in the same order: results and counters are bitwise identical. */
 int nbody_bvh_set_traversal(nbody_bvh* t, int mode);
 /* Launch order of the sweep: 0 = work items (groups that straddle a jump of the key order are cut in two and start first),

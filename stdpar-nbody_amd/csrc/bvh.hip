@@ -834,6 +834,88 @@ __global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* _
 }
 
 // ------------------------------------------------------------------------------------------------
+// K9, row sweeps: FOUR independent sweeps per wave, one per 16-lane row (traversal mode 6; an experiment that is kept because
+// its measurement is: profiles/r03/k9_row_sweep.txt).  The union of 16 Hilbert-adjacent walks is 23 % shorter than the union of
+// 64 (5.7k against 7.4k entries at config 4), but a row's position is no longer wave-uniform: the record comes through the
+// vector memory path (one address per row), the position lives in VGPRs, the row-wide conditions are cut out of ballots per
+// lane, and every scalar operation of the wave sweep's bookkeeping becomes a vector one.  Same tests in the same order per
+// body: bitwise the results of every other form.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D>
+__global__ __launch_bounds__(64) void bvh_force_row_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
+                                                           const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
+                                                           uint32_t count, T theta2, uint32_t nlevels) {
+  const uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x);
+  const uint32_t local = group * 64u + threadIdx.x;
+  const bool valid     = local < count;
+  const uint32_t bi    = first + (valid ? local : 0u);
+  const pair_consts<T> pc;
+  T xs[D], acc[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) {
+    xs[k]  = x[uint64_t(bi) * D + k];
+    acc[k] = T(0);
+  }
+  uint32_t key = valid ? 0u : 0xffffffffu;
+  // the row's position, the same value in its 16 lanes: packed key, 32 << (levels below), level-order index of the entry
+  uint32_t cur = 0, span = 32u << nlevels, idx = 0;
+  const uint32_t end_key = (sz << 5) - 1u;  // see bvh_force_wave_kernel
+  const uint32_t rshift  = threadIdx.x & 48u;
+  uint32_t budget        = (4u << nlevels) + 64u;  // a sweep visits every tree entry at most once: an exit every wave reaches
+  while (__builtin_amdgcn_ballot_w64(cur < end_key) != 0ull && budget-- != 0u) {
+    const bool live      = cur < end_key;
+    const tree_rec<T> rc = node[live ? idx : 0u];
+    const uint32_t right = (idx & 1u) ^ 1u;     // an entry is a right child iff its level-order index is even (root included)
+    const uint32_t ka = cur + span - right, kd = cur + 1u;
+    T d[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) d[k] = xs[k] - rc.v[k];
+    const T d2 = dist2_ref<T, D>(d);
+    T scaled;
+    {
+#pragma clang fp contract(off)
+      scaled = theta2 * d2;
+    }
+    const bool active = live && key == cur;
+    const bool approx = !(rc.v[D + 2] >= scaled);
+    const bool accept = active && approx, reject = active && !approx;
+    const uint64_t m_accept = __builtin_amdgcn_ballot_w64(accept);
+    if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc, d, d2, rc.v[D], pc);
+    key = accept ? ka : (reject ? kd : key);
+    const bool row_reject = ((__builtin_amdgcn_ballot_w64(reject) >> rshift) & 0xffffull) != 0ull;
+    const bool row_wait   = ((__builtin_amdgcn_ballot_w64(live && key < ka) >> rshift) & 0xffffull) != 0ull;
+    uint32_t mn = key;  // smallest key of the row (needed only when the row is behind; rows take their branches together)
+    if (__builtin_amdgcn_ballot_w64(live && !row_reject && row_wait) != 0ull) {
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const uint32_t other = uint32_t(__shfl_xor(int(mn), o, 16));
+        mn                   = other < mn ? other : mn;
+      }
+    }
+    if (live) {
+      if (row_reject) {  // some lane of the row opened the entry: its left child is the smallest key the row can hold
+        cur = kd;
+        idx = 2u * idx + 1u;
+        span >>= 1;
+      } else if (!row_wait) {  // ascend rule: left child -> sibling, right child -> parent + 1
+        cur = ka;
+        idx = right ? (idx >> 1) : idx + 1u;
+        span <<= right;
+      } else {  // a lane waits below the entry just left
+        cur                  = mn;
+        const uint32_t level = mn & 31u, shift = nlevels - level;
+        span                 = 32u << shift;
+        idx                  = ((1u << level) - 1u) + ((mn >> 5) >> shift);
+      }
+    }
+  }
+  if (valid) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K9, the sweep's step program written out as ISA (f64 described; the f32 text follows it).
 //
 // The sweep above is bound by the number of instructions a step issues (vector and scalar halves barely overlap: a wave's
@@ -1289,6 +1371,17 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const uint32_t crossover = sizeof(T) == 8 ? 4096u : 180000u;
   int traversal = t->traversal;
   if (const char* e = experiment_env("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // -DNBODY_EXPERIMENTS builds only
+  if (traversal == 6) {  // four 16-lane row sweeps per wave (experiment; no counters)
+    if (t->counters_on || t->nlevels > 26) {
+      set_error("traversal mode 6 (row sweeps) has no counters and needs nlevels <= 26");
+      return NBODY_ERR_ARG;
+    }
+    const uint32_t rblocks = (s->count + 63u) / 64u;
+    hipLaunchKernelGGL((bvh_force_row_kernel<T, D>), dim3(rblocks), dim3(64), 0, st, node, static_cast<T*>(s->a),
+                       static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz, s->first, s->count, th2, t->nlevels);
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
@@ -1462,7 +1555,7 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
 
 extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
-  NB_ARG(mode >= 0 && mode <= 5, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 6, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep), 6 (four 16-lane row sweeps per wave), got %d", mode);
   t->traversal = mode;
   return NBODY_OK;
 }

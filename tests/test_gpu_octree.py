@@ -10,8 +10,15 @@ from conftest import DT
 
 pytestmark = pytest.mark.gpu
 
+import json
+import os
+
 FORCE_TOL = {0: 2e-5, 1: 1e-12}
-TRAJ_TOL = {0: 2e-3, 1: 1e-11}
+# Float trajectories of the tree algorithms: MEASURED on the reference itself (tests/golden/calibrate_float_tolerance.py builds it
+# -O2 and -Ofast -march=native and runs bvh / octree, theta 0 and 0.5, 10 steps: its two builds drift apart by up to 8.0e-4 of the
+# position scale in 2D and 2.6e-6 in 3D); the tests allow 4x that spread, never less than the one-pass float floor 2e-5.
+_FLOAT_TOL = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "float_tolerance.json")))
+TRAJ_TOL = {0: {2: _FLOAT_TOL["float_tree_trajectory_rel_2d"], 3: _FLOAT_TOL["float_tree_trajectory_rel_3d"]}, 1: {2: 1e-11, 3: 1e-11}}
 
 
 def maxrel(a, b):
@@ -217,7 +224,7 @@ def test_trajectories_vs_reference_fixtures(nb, golden_positions):
         for step in range(1, case["steps"] + 1):
             nb.run(dev, "octree", 1, case["theta"])
             if step in case["frame_ids"]:
-                assert np.abs(dev.download().x - ref[k]).max() <= TRAJ_TOL[dtype] * scale, (name, step)
+                assert np.abs(dev.download().x - ref[k]).max() <= TRAJ_TOL[dtype][case["dim"]] * scale, (name, step)
                 k += 1
         dev.octree.info(dev.stream)
         dev.close()

@@ -1,29 +1,33 @@
 // K1 all-pairs force, K2 all-pairs-collapsed force, K3 leapfrog step — hand-written for gfx950.
 //
 // K1 (replaces src/all_pairs.h:14-27).  Bound: FP64/FP32 VALU issue (no MFMA: the inner body is
-// sub/FMA/rsq/rcp, not a contraction).  Structure:
+// sub/FMA/rsq, not a contraction).  Structure:
 //   * one lane per target body (R targets per lane), targets of a block held in VGPRs;
-//   * sources are packed (x, m) records visited in tiles of TJ; the source range of every tile is split over
-//     the JS waves that share a target group, so a small shard (N/8 bodies on one GPU) still puts >= 4 waves
-//     on every SIMD — one wave alone reaches only 75% of the FP64 issue rate
-//     (profiles/r01_valu_rates_microbench.txt);
-//   * wave partials are combined through LDS in a fixed order, so the result is deterministic and
-//     independent of how bodies are sharded over GPUs.
-//   Two ways of bringing a source record to the 64 lanes that all need the same one:
+//   * sources are packed (x, m) records visited in tiles of 512; every tile is cut into JS slices, one per wave of the
+//     block that shares a target group, and the tile sequence into source chunks over grid.y — both from sz alone, so a
+//     shard window (N/8 targets on one GPU) sums exactly as the whole system does and still fills the chip;
+//   * slice partials are combined through LDS in wave order, chunk sums by combine_chunks_kernel in chunk order:
+//     deterministic, and independent of how bodies are sharded over GPUs.
+//   Two ways of bringing a source record to the 64 lanes that all need the same one (bitwise the same result):
 //   - LDS tiles (all_pairs_force_kernel): tiles staged in LDS by all 256 lanes with a register prefetch of the
 //     next tile; the inner loop reads each record as an LDS broadcast (ds_read_b128) into VGPRs;
-//   - scalar stream (all_pairs_force_sgpr_kernel, default): the record is wave-uniform, so it belongs in SGPRs:
-//     a pre-pass packs the records once per call (32 B x N), every wave streams its slice with
-//     s_load_dwordx16 two batches deep and the VALU instructions take their source operands from SGPRs.
-//     No staging loads, no LDS traffic, no barriers in the loop, half the VGPRs (occupancy 8).  Same
-//     arithmetic in the same order: bitwise the LDS kernel's result; 3 % faster at every size measured
-//     (722 vs 746 ms at N = 2^20 on the same box) on a kernel that runs at the socket power cap.
+//   - scalar stream (all_pairs_force_sgpr_kernel, default from 2048 bodies): the record is wave-uniform, so it belongs in
+//     SGPRs: a pre-pass packs the records once per call (32 B x N), every wave streams its slice with
+//     s_load_dwordx16 two batches deep (inline asm) and the VALU instructions take their source operands from SGPRs.
+//     No staging loads, no LDS traffic, no barriers in the loop, half the VGPRs.
+//   Pair rule (common.hpp, pair_batch): f64 is reciprocal-free — 16 full-rate ops + v_rsq_f64 per pair on sparse systems
+//   (the launch-level far mode: the system's bounding box, reduced by extent_kernel before every call, says that few
+//   batches can hold a pair closer than 2), 17 + 1 on dense ones; pairs below 2^-16 take the guarded reciprocal form.
+//   Measured on one box, A/B against round 2's library (profiles/r03/ab_k1_far_mode.txt): N = 2^20 galaxy 629 -> 608 ms
+//   per pass = 36.2 TFLOP/s = 46.0 % of the 78.6 TF FP64 vector peak (round 2: 44.4 % on that box); dense (uniform) systems
+//   keep round 2's rule and time.
 //
 // K2 (replaces src/all_pairs.h:29-50, intended semantics).  Lanes run along the SOURCE axis (one
 // ordered pair per lane and step), each wave owns 64 targets whose positions it broadcasts with
-// v_readlane; the per-target partial over 64*KJ sources is reduced across the wavefront with DPP
-// cross-lane adds (the __shfl family compiles to ds_bpermute here), lane t keeps target t's sum, and
-// after the tile each wave issues D coalesced atomic adds.  grid.y splits the source range so small N still fills the chip.
+// v_readlane; the partial sums of 16 (f32) / 8 (f64) targets stay in registers over a whole 2048- / 1024-record tile and are
+// reduced together by a transposed DPP butterfly (transpose_reduce), lane t keeps target t's sum, and after its tiles each
+// wave issues D coalesced atomic adds.  grid.y splits the source range so small N still fills the chip.
+// Config 3 (f32, N = 262 144): 23.9 ms = 36.5 % of the FP32 vector peak.
 //
 // K3 (replaces src/system.h:52-60).  Pure HBM stream (7*D*sizeof(T) bytes/body), flat elementwise
 // over count*D scalars, FP contraction off so it is bit-identical to the reference's x86 -O2 build.

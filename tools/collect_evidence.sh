@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session that produces everything kept under profiles/<tag>/: the bench line, its rocprofv3 summaries (stamped),
 # the per-config timings, the reference-shaped benchmark logs + scraped tables, and PMC passes of K2 and K9.
-# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r02
-TAG=${1:-r02}
+# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r03
+TAG=${1:-r03}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -23,5 +23,9 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k2 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 262144 -s 12 --precision float --algorithm all-pairs-collapsed --workload uniform --csv-total > $O/trace_k2.txt 2>&1
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_k9 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 1000000 -s 12 --precision double --algorithm bvh --workload galaxy --csv-total > $O/trace_k9.txt 2>&1
 timeout -k 10 120 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_energy -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 262144 -s 3 --precision double --algorithm all-pairs --workload galaxy --csv-detailed --save energy > $O/trace_energy.txt 2>&1
-cd $R; timeout -k 10 120 python3 tools/time_energy.py > $O/energy_times.txt 2>&1; timeout -k 10 120 python3 tools/time_octree.py > $O/octree_times.txt 2>&1; cd /tmp
+cd $R; timeout -k 10 120 python3 tools/time_energy.py > $O/energy_times.txt 2>&1
+{ timeout -k 10 120 python3 tools/time_octree.py 1000000 double; timeout -k 10 120 python3 tools/time_octree.py 1000000 float; timeout -k 10 60 python3 tools/time_octree.py 100000 float; } > $O/octree_times.txt 2>&1
+timeout -k 10 200 python3 tools/time_step_graph.py > $O/step_graph.txt 2>&1; timeout -k 10 200 python3 tools/time_step_graph.py float >> $O/step_graph.txt 2>&1
+PREC=float TAG=pmc_otf bash tools/pmc_kernel.sh ot_force_isa_f32 octree 1000000 "$C1" "$C2" "FETCH_SIZE" > $O/pmc_octree_walk_f32.txt 2>&1
+cd /tmp
 find $O/trace_k2 $O/trace_k9 $O/trace_energy -name "*kernel_stats.csv" | while read f; do echo $f; head -6 $f; done

@@ -17,6 +17,7 @@
 // the opening test), only the accumulated force uses the fast pair math of common.hpp.
 #include "common.hpp"
 #include "radix_sort.hpp"
+#include "to_sgpr.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -1220,8 +1221,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     // An accepted entry satisfies width^2 < fl(theta^2 d2); with d2 < 2^-16 that is <= theta^2 * 2^-16 (exact scaling), so only
     // records whose width^2 has a high word <= that bound's — and body records, width^2 = -1, negative as an integer — can hold
     // a near pair: a scalar compare decides whether the wave looks at all.
-    int khi, khi_v = int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1;
-    asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(khi) : "v"(khi_v));  // (the product is computed by the vector unit)
+    int khi = to_sgpr(int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1);  // (a VALU product)
     asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
     double d0, d1, d2, r2, t, y, y2, e, p, q, ms;
     uint32_t w2s;

@@ -23,6 +23,7 @@
 // thread each (ot_build_deep_kernel), so the tree has the reference's shape at any depth.
 #include "common.hpp"
 #include "radix_sort.hpp"
+#include "to_sgpr.hpp"
 
 #include <cstdlib>
 #include <cstring>
@@ -985,26 +986,37 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   "v_fmac_f64_e32 %[w], %[w], %[g]\n\t"
 
 // One visit round of ot_force_kernel written out as ISA (double, 3D): see ot_force_isa_kernel.
-#define OT_ISA_TEXT(CNT_N, CNT_T)                                                                                         \
+#define OT_KEEP(...) __VA_ARGS__
+#define OT_DROP(...) ""
+// record loads of a round: 3D (p0,p1) | (p2,m) | (fc,depth) from a 320-byte group; 2D (p0,p1) | m | (fc,depth) from a 128-byte one
+#define OT_LOADS_F64_D3                                                                                                   \
+  "v_mad_u32_u24 %[oa], %[cur], %[gsz], %[cc16]\n\t"                                                                      \
+  "v_mad_u32_u24 %[of], %[cur], %[gsz], %[cc8]\n\t"                                                                       \
+  "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
+  "global_load_dwordx4 v[58:61], %[oa], %[groups] offset:128\n\t"                                                         \
+  "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"
+#define OT_LOADS_F64_D2                                                                                                   \
+  "v_mad_u32_u24 %[oa], %[cur], %[gsz], %[cc16]\n\t"                                                                      \
+  "v_mad_u32_u24 %[of], %[cur], %[gsz], %[cc8]\n\t"                                                                       \
+  "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
+  "global_load_dwordx2 v[60:61], %[of], %[groups] offset:-32\n\t"                                                         \
+  "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"
+#define OT_ISA_TEXT(Z, LOADS, MASK, SSH, CNT_N, CNT_T)                                                                                      \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
   "v_cmp_ne_u32_e32 vcc, 0, %[more]\n\t"                                                                                  \
   "s_and_b64 exec, exec, vcc\n\t"                                                                                         \
   "s_cbranch_execz .LOTend%=\n"                                                                                           \
   ".LOTtop%=:\n\t"                                                                                                        \
-  "v_mad_u32_u24 %[oa], %[cur], %[s320], %[cc16]\n\t"                                                                     \
-  "v_mad_u32_u24 %[of], %[cur], %[s320], %[cc8]\n\t"                                                                      \
-  "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
-  "global_load_dwordx4 v[58:61], %[oa], %[groups] offset:128\n\t"                                                         \
-  "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"                                                                    \
+  LOADS                                                                                                                   \
   CNT_N                                                                                                                   \
   "s_waitcnt vmcnt(2)\n\t"                                                                                                \
   "v_add_f64 %[d0], v[54:55], -%[xi0]\n\t"                                                                                \
   "v_add_f64 %[d1], v[56:57], -%[xi1]\n\t"                                                                                \
   "v_fma_f64 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
-  "s_waitcnt vmcnt(1)\n\t"                                                                                                \
-  "v_add_f64 %[d2], v[58:59], -%[xi2]\n\t"                                                                                \
+  Z("s_waitcnt vmcnt(1)\n\t"                                                                                              \
+    "v_add_f64 %[d2], v[58:59], -%[xi2]\n\t")                                                                             \
   "v_fmac_f64_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
-  "v_fmac_f64_e32 %[r2], %[d2], %[d2]\n\t"                                                                                \
+  Z("v_fmac_f64_e32 %[r2], %[d2], %[d2]\n\t")                                                                             \
   "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
   "s_waitcnt vmcnt(0)\n\t"                                                                                                \
   "v_sub_u32_e32 %[t], 0, v63\n\t"                                                                                        \
@@ -1033,23 +1045,23 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   ".LOTacc%=:\n\t"                                                                                                        \
   "v_fmac_f64_e32 %[acc0], %[w], %[d0]\n\t"                                                                               \
   "v_fmac_f64_e32 %[acc1], %[w], %[d1]\n\t"                                                                               \
-  "v_fmac_f64_e32 %[acc2], %[w], %[d2]\n"                                                                                 \
+  Z("v_fmac_f64_e32 %[acc2], %[w], %[d2]\n\t")                                                                            \
   ".LOTnotake%=:\n\t"                                                                                                     \
   /* the children to open go on the body's stack in reverse child order; the 2^D lanes of a body pop the same entry */    \
   "s_mov_b64 exec, %[act]\n\t"                                                                                            \
   "v_lshrrev_b64 v[52:53], %[gshift], %[open]\n\t"                                                                        \
-  "v_and_b32_e32 v52, 0xff, v52\n\t"                                                                                      \
+  "v_and_b32_e32 v52, " MASK ", v52\n\t"                                                                                    \
   "v_bcnt_u32_b32 %[nsp], v52, %[sp]\n\t"                                                                                 \
   "s_and_b64 exec, %[open], %[open]\n\t"                                                                                  \
   "v_lshrrev_b32_e32 v53, %[ccp1], v52\n\t"                                                                               \
   "v_bcnt_u32_b32 v53, v53, %[sp]\n\t"                                                                                    \
-  "v_lshl_add_u32 v53, v53, 5, %[stk]\n\t"                                                                                \
+  "v_lshl_add_u32 v53, v53, " SSH ", %[stk]\n\t"                                                                            \
   "ds_write_b32 v53, v62\n\t"                                                                                             \
   "s_mov_b64 exec, %[act]\n\t"                                                                                            \
   "v_add_u32_e32 %[sp], -1, %[nsp]\n\t"                                                                                   \
   "v_cmpx_gt_u32_e64 %[act], %[depth], %[sp]\n\t"                                                                         \
   "s_cbranch_execz .LOTend%=\n\t"                                                                                         \
-  "v_lshl_add_u32 v53, %[sp], 5, %[stk]\n\t"                                                                              \
+  "v_lshl_add_u32 v53, %[sp], " SSH ", %[stk]\n\t"                                                                            \
   "ds_read_b32 %[cur], v53\n\t"                                                                                           \
   "s_add_i32 %[guard], %[guard], -1\n\t"                                                                                  \
   "s_cmp_lg_u32 %[guard], 0\n\t"                                                                                          \
@@ -1061,8 +1073,8 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   "v_mul_f64 v[52:53], %[d0], %[d0]\n\t"                                                                                  \
   "v_mul_f64 v[54:55], %[d1], %[d1]\n\t"                                                                                  \
   "v_add_f64 v[52:53], v[52:53], v[54:55]\n\t"                                                                            \
-  "v_mul_f64 v[54:55], %[d2], %[d2]\n\t"                                                                                  \
-  "v_add_f64 v[52:53], v[54:55], v[52:53]\n\t"                                                                            \
+  Z("v_mul_f64 v[54:55], %[d2], %[d2]\n\t"                                                                                \
+    "v_add_f64 v[52:53], v[54:55], v[52:53]\n\t")                                                                         \
   "v_cmp_gt_f64_e32 vcc, %[sqmin], v[52:53]\n\t"                                                                          \
   "s_nop 1\n\t"                                                                                                           \
   "v_mov_b32_e32 %[oa], 0x100\n\t"                                                                                          \
@@ -1120,15 +1132,6 @@ __global__ __launch_bounds__(64) void ot_force_kernel(const ot_node<T>* __restri
   ".LOTend%=:\n\t"                                                                                                        \
   "s_mov_b64 exec, %[sv]"
 
-// A wave-uniform double that the vector unit computed, moved to an SGPR pair (opaque to the optimizer, which would fold a
-// readfirstlane of a value it knows to be uniform and then fail to satisfy an "s" constraint).
-__device__ __forceinline__ double ot_to_sgpr(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  uint32_t lo, hi;
-  asm volatile("v_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3" : "=s"(lo), "=s"(hi) : "v"(uint32_t(b)), "v"(uint32_t(b >> 32)));
-  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
-}
-
 // The walk of ot_force_kernel for double precision in 3D with its visit round written as ISA — the same tests, the same
 // arithmetic in the same order, bitwise the same results, counters and flags.  hipcc's schedule of the C++ round is ~96
 // instructions (50 VALU): predicated weights, mask round trips through v_cndmask/v_cmp, one saveexec/branch pair per `if`.
@@ -1139,20 +1142,19 @@ __device__ __forceinline__ double ot_to_sgpr(double v) {
 // LDS, where the hardware drops it; the lane then leaves and reports kFlagStack).  The records of the round live in v[52:63] (their halves are addressed
 // separately, which an asm operand cannot express).  Group offsets are 32 bits: the host uses this kernel while the group
 // array is below 4 GiB (N <= 1.3e7).
-template <bool COUNT>
+template <int D, bool COUNT>
 __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>* __restrict__ rootrec,
-                                                          const ot_group<double, 3>* __restrict__ groups,
+                                                          const ot_group<double, D>* __restrict__ groups,
                                                           const uint32_t* __restrict__ list, uint32_t nlist,
                                                           const double* __restrict__ x, double* __restrict__ a, double c,
                                                           uint32_t first, double theta, uint32_t capacity,
                                                           const double* __restrict__ root, uint32_t* __restrict__ flags,
                                                           uint32_t* __restrict__ counters) {
   using T = double;
-  constexpr int D = 3;
-  constexpr uint32_t NCH = 8, GPW = 8;
+  constexpr uint32_t NCH = 1u << D, GPW = 64u / NCH;
   constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;
-  static_assert(sizeof(ot_group<double, 3>) == 320, "the round addresses 320-byte sibling groups");
-  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * 8 + g) * 4
+  static_assert(sizeof(ot_group<double, 3>) == 320 && sizeof(ot_group<double, 2>) == 128, "the round addresses 320- / 128-byte sibling groups");
+  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * GPW + g) * 4
   const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
   const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
   const bool valid    = t < nlist;
@@ -1160,20 +1162,20 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   const ot_theta<T> th(theta);
   const pair_consts<T> pc;
   const T root_side = root[D];
-  T xi[D], acc[D];
+  T xi[3] = {T(0), T(0), T(0)}, acc[3] = {T(0), T(0), T(0)};  // (the third pair is an unused operand in 2D)
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
-    acc[k] = T(0);
-  }
+  for (int k = 0; k < D; ++k) xi[k] = valid ? x[uint64_t(body) * D + k] : T(0);
   uint32_t c_nodes = 0, c_terms = 0;
   uint32_t cur = 0;
   bool more = false;
   if (valid) {  // the root is examined alone, exactly as in ot_force_kernel
     const ot_node<T> nd = *rootrec;
-    T di[D];
+    T di[D], a0[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
+    for (int k = 0; k < D; ++k) {
+      di[k] = nd.p[k] - xi[k];
+      a0[k] = T(0);
+    }
     const T d2f     = ot_dist2_fused<T, D>(di);
     const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;
@@ -1181,8 +1183,10 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
     {
       const bool on0    = take && cc == 0;
       const uint64_t m0 = __builtin_amdgcn_ballot_w64(on0);
-      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, acc, di, nd.m, d2f, y0, pc);
+      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, a0, di, nd.m, d2f, y0, pc);
     }
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = a0[k];
     if (COUNT && cc == 0) {
       c_nodes = 1;
       c_terms = take;
@@ -1192,13 +1196,13 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   }
   // the rounds
   uint32_t more_v = more ? 1u : 0u, sp = 0, nsp = 0, gflag = 0, guard = capacity;
-  const uint32_t cc16 = cc * 16u, cc8 = 256u + cc * 8u, gshift = threadIdx.x & 56u, ccp1 = cc + 1u;
+  const uint32_t cc16 = cc * 16u, cc8 = (D == 3 ? 256u : 96u) + cc * 8u, gshift = threadIdx.x & (64u - NCH), ccp1 = cc + 1u;
   const uint32_t stk = uint32_t(reinterpret_cast<uintptr_t>(&stack[0][g]));  // LDS byte address (low word of the flat one)
-  double lo = ot_to_sgpr(th.lo), hi = ot_to_sgpr(th.hi), thx = ot_to_sgpr(th.exact), c35 = 0x1p35, tiny = ot_consts<T>::tiny,
-         eps = ot_consts<T>::eps, m3eps = -(3.0 * ot_consts<T>::eps), sqmin = 0x1p-767, rs = ot_to_sgpr(root_side);
+  double lo = to_sgpr(th.lo), hi = to_sgpr(th.hi), thx = to_sgpr(th.exact), c35 = 0x1p35, tiny = ot_consts<T>::tiny,
+         eps = ot_consts<T>::eps, m3eps = -(3.0 * ot_consts<T>::eps), sqmin = 0x1p-767, rs = to_sgpr(root_side);
   uint64_t nearhi = uint64_t(ot_near<T>::bits) << 32;
-  uint32_t s320 = 320u, depth = DEPTH, c260 = 0x260u;
-  asm volatile("" : "+s"(c35), "+s"(tiny), "+s"(eps), "+s"(m3eps), "+s"(sqmin), "+s"(nearhi), "+s"(s320), "+s"(depth), "+s"(c260));
+  uint32_t gsz = uint32_t(sizeof(ot_group<double, D>)), depth = DEPTH, c260 = 0x260u;
+  asm volatile("" : "+s"(c35), "+s"(tiny), "+s"(eps), "+s"(m3eps), "+s"(sqmin), "+s"(nearhi), "+s"(gsz), "+s"(depth), "+s"(c260));
   double d0, d1, d2, r2, y, y2, e, p, gq, w;
   uint32_t oa, of, tt;
   uint64_t nonleaf, st, so, so2, take, open, act, sv, near;
@@ -1211,13 +1215,17 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   : [more] "v"(more_v), [groups] "s"(groups), [xi0] "v"(xi[0]), [xi1] "v"(xi[1]), [xi2] "v"(xi[2]), [cc16] "v"(cc16),     \
     [cc8] "v"(cc8), [gshift] "v"(gshift), [ccp1] "v"(ccp1), [stk] "v"(stk), [k15] "v"(pc.k15), [k1875] "s"(pc.k1875),       \
     [lo] "s"(lo), [hi] "s"(hi), [theta] "s"(thx), [c35] "s"(c35), [tiny] "s"(tiny), [eps] "s"(eps), [m3eps] "s"(m3eps),    \
-    [sqmin] "s"(sqmin), [nearhi] "s"(nearhi), [rootside] "s"(rs), [s320] "s"(s320), [depth] "s"(depth), [c260] "s"(c260)                                                                                     \
+    [sqmin] "s"(sqmin), [nearhi] "s"(nearhi), [rootside] "s"(rs), [gsz] "s"(gsz), [depth] "s"(depth), [c260] "s"(c260)                                                                                     \
   : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
 #define OT_CNT_OPERANDS [cn] "+v"(c_nodes), [ct] "+v"(c_terms),
-  if constexpr (COUNT) asm volatile(OT_ISA_TEXT("v_add_u32_e32 %[cn], 1, %[cn]\n\t", "v_add_u32_e32 %[ct], 1, %[ct]\n\t") OT_OPERANDS);
+#define OT_CN "v_add_u32_e32 %[cn], 1, %[cn]\n\t"
+#define OT_CT "v_add_u32_e32 %[ct], 1, %[ct]\n\t"
+  if constexpr (COUNT && D == 3) asm volatile(OT_ISA_TEXT(OT_KEEP, OT_LOADS_F64_D3, "0xff", "5", OT_CN, OT_CT) OT_OPERANDS);
+  if constexpr (COUNT && D == 2) asm volatile(OT_ISA_TEXT(OT_DROP, OT_LOADS_F64_D2, "0xf", "6", OT_CN, OT_CT) OT_OPERANDS);
 #undef OT_CNT_OPERANDS
 #define OT_CNT_OPERANDS
-  if constexpr (!COUNT) asm volatile(OT_ISA_TEXT("", "") OT_OPERANDS);
+  if constexpr (!COUNT && D == 3) asm volatile(OT_ISA_TEXT(OT_KEEP, OT_LOADS_F64_D3, "0xff", "5", "", "") OT_OPERANDS);
+  if constexpr (!COUNT && D == 2) asm volatile(OT_ISA_TEXT(OT_DROP, OT_LOADS_F64_D2, "0xf", "6", "", "") OT_OPERANDS);
 #undef OT_CNT_OPERANDS
 #undef OT_OPERANDS
   if (more && nsp > DEPTH && cc == 0) atomicOr(flags, kFlagStack);  // a stack ran full: reported by nbody_octree_info
@@ -1257,24 +1265,24 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   "v_mul_f32_e32 %[t], %[m3eps], %[y]\n\t"                                                                                \
   "v_fmac_f32_e32 %[w], %[w], %[t]\n\t"
 
-#define OT_ISA_TEXT_F32(CNT_N, CNT_T)                                                                                     \
+#define OT_ISA_TEXT_F32(Z, MASK, SSH, CNT_N, CNT_T)                                                                                  \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
   "v_cmp_ne_u32_e32 vcc, 0, %[more]\n\t"                                                                                  \
   "s_and_b64 exec, exec, vcc\n\t"                                                                                         \
   "s_cbranch_execz .LOFend%=\n"                                                                                           \
   ".LOFtop%=:\n\t"                                                                                                        \
-  "v_mad_u32_u24 %[oa], %[cur], %[s192], %[cc16]\n\t"                                                                     \
-  "v_mad_u32_u24 %[of], %[cur], %[s192], %[cc8]\n\t"                                                                      \
+  "v_mad_u32_u24 %[oa], %[cur], %[gsz], %[cc16]\n\t"                                                                      \
+  "v_mad_u32_u24 %[of], %[cur], %[gsz], %[cc8]\n\t"                                                                       \
   "global_load_dwordx4 v[54:57], %[oa], %[groups]\n\t"                                                                    \
   "global_load_dwordx2 v[62:63], %[of], %[groups]\n\t"                                                                    \
   CNT_N                                                                                                                   \
   "s_waitcnt vmcnt(1)\n\t"                                                                                                \
   "v_sub_f32_e32 %[d0], v54, %[xi0]\n\t"                                                                                  \
   "v_sub_f32_e32 %[d1], v55, %[xi1]\n\t"                                                                                  \
-  "v_sub_f32_e32 %[d2], v56, %[xi2]\n\t"                                                                                  \
+  Z("v_sub_f32_e32 %[d2], v56, %[xi2]\n\t")                                                                               \
   "v_fma_f32 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
   "v_fmac_f32_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
-  "v_fmac_f32_e32 %[r2], %[d2], %[d2]\n\t"                                                                                \
+  Z("v_fmac_f32_e32 %[r2], %[d2], %[d2]\n\t")                                                                             \
   "v_rsq_f32_e32 %[y], %[r2]\n\t"                                                                                         \
   "s_waitcnt vmcnt(0)\n\t"                                                                                                \
   "v_sub_u32_e32 %[t], 0, v63\n\t"                                                                                        \
@@ -1303,22 +1311,22 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   ".LOFacc%=:\n\t"                                                                                                        \
   "v_fmac_f32_e32 %[acc0], %[w], %[d0]\n\t"                                                                               \
   "v_fmac_f32_e32 %[acc1], %[w], %[d1]\n\t"                                                                               \
-  "v_fmac_f32_e32 %[acc2], %[w], %[d2]\n"                                                                                 \
+  Z("v_fmac_f32_e32 %[acc2], %[w], %[d2]\n\t")                                                                            \
   ".LOFnotake%=:\n\t"                                                                                                     \
   "s_mov_b64 exec, %[act]\n\t"                                                                                            \
   "v_lshrrev_b64 v[52:53], %[gshift], %[open]\n\t"                                                                        \
-  "v_and_b32_e32 v52, 0xff, v52\n\t"                                                                                      \
+  "v_and_b32_e32 v52, " MASK ", v52\n\t"                                                                                    \
   "v_bcnt_u32_b32 %[nsp], v52, %[sp]\n\t"                                                                                 \
   "s_and_b64 exec, %[open], %[open]\n\t"                                                                                  \
   "v_lshrrev_b32_e32 v53, %[ccp1], v52\n\t"                                                                               \
   "v_bcnt_u32_b32 v53, v53, %[sp]\n\t"                                                                                    \
-  "v_lshl_add_u32 v53, v53, 5, %[stk]\n\t"                                                                                \
+  "v_lshl_add_u32 v53, v53, " SSH ", %[stk]\n\t"                                                                            \
   "ds_write_b32 v53, v62\n\t"                                                                                             \
   "s_mov_b64 exec, %[act]\n\t"                                                                                            \
   "v_add_u32_e32 %[sp], -1, %[nsp]\n\t"                                                                                   \
   "v_cmpx_gt_u32_e64 %[act], %[depth], %[sp]\n\t"                                                                         \
   "s_cbranch_execz .LOFend%=\n\t"                                                                                         \
-  "v_lshl_add_u32 v53, %[sp], 5, %[stk]\n\t"                                                                              \
+  "v_lshl_add_u32 v53, %[sp], " SSH ", %[stk]\n\t"                                                                            \
   "ds_read_b32 %[cur], v53\n\t"                                                                                           \
   "s_add_i32 %[guard], %[guard], -1\n\t"                                                                                  \
   "s_cmp_lg_u32 %[guard], 0\n\t"                                                                                          \
@@ -1330,8 +1338,8 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   "v_mul_f32_e32 v52, %[d0], %[d0]\n\t"                                                                                   \
   "v_mul_f32_e32 v53, %[d1], %[d1]\n\t"                                                                                   \
   "v_add_f32_e32 v52, v52, v53\n\t"                                                                                       \
-  "v_mul_f32_e32 v53, %[d2], %[d2]\n\t"                                                                                   \
-  "v_add_f32_e32 v52, v53, v52\n\t"                                                                                       \
+  Z("v_mul_f32_e32 v53, %[d2], %[d2]\n\t"                                                                                 \
+    "v_add_f32_e32 v52, v53, v52\n\t")                                                                                    \
   "v_mul_f32_e32 v53, 0x4f800000, v52\n\t"                                                                                \
   "v_cmp_gt_f32_e32 vcc, %[sqmin], v52\n\t"                                                                               \
   "s_nop 1\n\t"                                                                                                           \
@@ -1390,26 +1398,19 @@ __global__ __launch_bounds__(64) void ot_force_isa_kernel(const ot_node<double>*
   ".LOFend%=:\n\t"                                                                                                        \
   "s_mov_b64 exec, %[sv]"
 
-__device__ __forceinline__ float ot_to_sgpr(float v) {
-  uint32_t r;
-  asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(r) : "v"(__builtin_bit_cast(uint32_t, v)));
-  return __builtin_bit_cast(float, r);
-}
-
-template <bool COUNT>
+template <int D, bool COUNT>
 __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<float>* __restrict__ rootrec,
-                                                              const ot_group<float, 3>* __restrict__ groups,
+                                                              const ot_group<float, D>* __restrict__ groups,
                                                               const uint32_t* __restrict__ list, uint32_t nlist,
                                                               const float* __restrict__ x, float* __restrict__ a, float c,
                                                               uint32_t first, float theta, uint32_t capacity,
                                                               const float* __restrict__ root, uint32_t* __restrict__ flags,
                                                               uint32_t* __restrict__ counters) {
   using T = float;
-  constexpr int D = 3;
-  constexpr uint32_t NCH = 8, GPW = 8;
+  constexpr uint32_t NCH = 1u << D, GPW = 64u / NCH;
   constexpr uint32_t DEPTH = (NCH - 1u) * kMaxLevels<D> + NCH;
-  static_assert(sizeof(ot_group<float, 3>) == 192, "the round addresses 192-byte sibling groups");
-  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * 8 + g) * 4
+  static_assert(sizeof(ot_group<float, 3>) == 192 && sizeof(ot_group<float, 2>) == 128, "the round addresses 192- / 128-byte sibling groups");
+  __shared__ uint32_t stack[DEPTH][GPW];  // entry-major: slot i of body g at (i * GPW + g) * 4
   const uint32_t g = threadIdx.x / NCH, cc = threadIdx.x % NCH;
   const uint32_t t    = ot_xcd_contiguous_block(blockIdx.x, gridDim.x) * GPW + g;
   const bool valid    = t < nlist;
@@ -1417,20 +1418,20 @@ __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<floa
   const ot_theta<T> th(theta);
   const pair_consts<T> pc;
   const T root_side = root[D];
-  T xi[D], acc[D];
+  T xi[3] = {T(0), T(0), T(0)}, acc[3] = {T(0), T(0), T(0)};  // (the third pair is an unused operand in 2D)
 #pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xi[k]  = valid ? x[uint64_t(body) * D + k] : T(0);
-    acc[k] = T(0);
-  }
+  for (int k = 0; k < D; ++k) xi[k] = valid ? x[uint64_t(body) * D + k] : T(0);
   uint32_t c_nodes = 0, c_terms = 0;
   uint32_t cur = 0;
   bool more = false;
   if (valid) {  // the root is examined alone, exactly as in ot_force_kernel
     const ot_node<T> nd = *rootrec;
-    T di[D];
+    T di[D], a0[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) di[k] = nd.p[k] - xi[k];
+    for (int k = 0; k < D; ++k) {
+      di[k] = nd.p[k] - xi[k];
+      a0[k] = T(0);
+    }
     const T d2f     = ot_dist2_fused<T, D>(di);
     const T y0      = ot_rsq(d2f);
     const bool leaf = nd.fc >= kOtBody;
@@ -1438,8 +1439,10 @@ __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<floa
     {
       const bool on0    = take && cc == 0;
       const uint64_t m0 = __builtin_amdgcn_ballot_w64(on0);
-      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, acc, di, nd.m, d2f, y0, pc);
+      if (m0 != 0ull) ot_accumulate<T, D>(on0, m0, a0, di, nd.m, d2f, y0, pc);
     }
+#pragma unroll
+    for (int k = 0; k < D; ++k) acc[k] = a0[k];
     if (COUNT && cc == 0) {
       c_nodes = 1;
       c_terms = take;
@@ -1448,12 +1451,12 @@ __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<floa
     cur  = nd.fc;
   }
   uint32_t more_v = more ? 1u : 0u, sp = 0, nsp = 0, gflag = 0, guard = capacity;
-  const uint32_t cc16 = cc * 16u, cc8 = 128u + cc * 8u, gshift = threadIdx.x & 56u, ccp1 = cc + 1u;
+  const uint32_t cc16 = cc * 16u, cc8 = (D == 3 ? 128u : 64u) + cc * 8u, gshift = threadIdx.x & (64u - NCH), ccp1 = cc + 1u;
   const uint32_t stk = uint32_t(reinterpret_cast<uintptr_t>(&stack[0][g]));
-  float lo = ot_to_sgpr(th.lo), hi = ot_to_sgpr(th.hi), thx = ot_to_sgpr(th.exact), tiny = ot_consts<T>::tiny, eps = ot_consts<T>::eps,
-        meps = -ot_consts<T>::eps, m3eps = -(3.0f * ot_consts<T>::eps), sqmin = 0x1p-96f, rs = ot_to_sgpr(root_side);
-  uint32_t nearbits = ot_near<T>::bits, s192 = 192u, depth = DEPTH;
-  asm volatile("" : "+s"(tiny), "+s"(eps), "+s"(meps), "+s"(m3eps), "+s"(sqmin), "+s"(nearbits), "+s"(s192), "+s"(depth));
+  float lo = to_sgpr(th.lo), hi = to_sgpr(th.hi), thx = to_sgpr(th.exact), tiny = ot_consts<T>::tiny, eps = ot_consts<T>::eps,
+        meps = -ot_consts<T>::eps, m3eps = -(3.0f * ot_consts<T>::eps), sqmin = 0x1p-96f, rs = to_sgpr(root_side);
+  uint32_t nearbits = ot_near<T>::bits, gsz = uint32_t(sizeof(ot_group<float, D>)), depth = DEPTH;
+  asm volatile("" : "+s"(tiny), "+s"(eps), "+s"(meps), "+s"(m3eps), "+s"(sqmin), "+s"(nearbits), "+s"(gsz), "+s"(depth));
   float d0, d1, d2, r2, y, gq, w, tt;
   uint32_t oa, of;
   uint64_t nonleaf, st, so, so2, take, open, act, sv, near;
@@ -1466,13 +1469,15 @@ __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<floa
   : [more] "v"(more_v), [groups] "s"(groups), [xi0] "v"(xi[0]), [xi1] "v"(xi[1]), [xi2] "v"(xi[2]), [cc16] "v"(cc16),     \
     [cc8] "v"(cc8), [gshift] "v"(gshift), [ccp1] "v"(ccp1), [stk] "v"(stk), [lo] "s"(lo), [hi] "s"(hi), [theta] "s"(thx),  \
     [tiny] "s"(tiny), [eps] "s"(eps), [meps] "s"(meps), [m3eps] "s"(m3eps), [sqmin] "s"(sqmin), [nearbits] "s"(nearbits),  \
-    [rootside] "s"(rs), [s192] "s"(s192), [depth] "s"(depth)                                                              \
+    [rootside] "s"(rs), [gsz] "s"(gsz), [depth] "s"(depth)                                                              \
   : "vcc", "scc", "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63"
 #define OT_CNT_OPERANDS [cn] "+v"(c_nodes), [ct] "+v"(c_terms),
-  if constexpr (COUNT) asm volatile(OT_ISA_TEXT_F32("v_add_u32_e32 %[cn], 1, %[cn]\n\t", "v_add_u32_e32 %[ct], 1, %[ct]\n\t") OT_OPERANDS);
+  if constexpr (COUNT && D == 3) asm volatile(OT_ISA_TEXT_F32(OT_KEEP, "0xff", "5", OT_CN, OT_CT) OT_OPERANDS);
+  if constexpr (COUNT && D == 2) asm volatile(OT_ISA_TEXT_F32(OT_DROP, "0xf", "6", OT_CN, OT_CT) OT_OPERANDS);
 #undef OT_CNT_OPERANDS
 #define OT_CNT_OPERANDS
-  if constexpr (!COUNT) asm volatile(OT_ISA_TEXT_F32("", "") OT_OPERANDS);
+  if constexpr (!COUNT && D == 3) asm volatile(OT_ISA_TEXT_F32(OT_KEEP, "0xff", "5", "", "") OT_OPERANDS);
+  if constexpr (!COUNT && D == 2) asm volatile(OT_ISA_TEXT_F32(OT_DROP, "0xf", "6", "", "") OT_OPERANDS);
 #undef OT_CNT_OPERANDS
 #undef OT_OPERANDS
   if (more && nsp > DEPTH && cc == 0) atomicOr(flags, kFlagStack);
@@ -1643,34 +1648,32 @@ static int ot_force_run(nbody_octree* t, const nbody_state* s, double theta, hip
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,                     \
                      static_cast<T>(theta), budget, static_cast<const T*>(t->root),                                        \
                      t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
-  // 3D: the visit round written as ISA (ot_force_isa_kernel, ot_force_isa_f32_kernel), while 24-bit group numbers times the group
+  // the visit round written as ISA (ot_force_isa_kernel, ot_force_isa_f32_kernel; 2D and 3D), while 24-bit group numbers times the group
   // size stay inside 32-bit offsets; nbody_octree_set_walk(t, 1) keeps the compiler-scheduled kernel (tests compare the two bitwise)
   bool isa = false;
-  if constexpr (D == 3) {
+  {
     const char* fe = experiment_env("NBODY_OT_FORM");  // -DNBODY_EXPERIMENTS builds only
-    isa = t->walk != 1 && !(fe && fe[0] == '1') && uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32) &&
-          t->max_cells < (1u << 24);
+    isa = t->walk != 1 && !(fe && fe[0] == '1') &&
+          uint64_t(t->max_cells) * sizeof(ot_group<T, D>) < (1ull << 32) && t->max_cells < (1u << 24);
   }
   if (t->walk == 2 && !isa) {
-    set_error("octree walk: the ISA visit round exists in 3D (and for trees within 32-bit group offsets) only");
+    set_error("octree walk: the ISA visit round needs the tree within 24-bit group numbers and 32-bit group offsets");
     return NBODY_ERR_ARG;
   }
   if (isa) {
-    if constexpr (D == 3) {
-#define NB_OT_ISA(KERN, CNT)                                                                                                 \
-  hipLaunchKernelGGL((KERN<CNT>), dim3(blocks), dim3(64), 0, st, rootrec, static_cast<const ot_group<T, D>*>(t->groups), list, \
-                     s->count, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,           \
-                     static_cast<T>(theta), budget, static_cast<const T*>(t->root), t->lvl_count + (kMaxLevels<3> + 2),      \
-                     t->counters)
-      if constexpr (sizeof(T) == 8) {
-        if (t->counters_on) NB_OT_ISA(ot_force_isa_kernel, true);
-        else NB_OT_ISA(ot_force_isa_kernel, false);
-      } else {
-        if (t->counters_on) NB_OT_ISA(ot_force_isa_f32_kernel, true);
-        else NB_OT_ISA(ot_force_isa_f32_kernel, false);
-      }
-#undef NB_OT_ISA
+#define NB_OT_ISA(KERN, CNT)                                                                                                  \
+  hipLaunchKernelGGL((KERN<D, CNT>), dim3(blocks), dim3(64), 0, st, rootrec, static_cast<const ot_group<T, D>*>(t->groups), list, \
+                     s->count, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->first,            \
+                     static_cast<T>(theta), budget, static_cast<const T*>(t->root),                                           \
+                     t->lvl_count + ((D == 3 ? kMaxLevels<3> : kMaxLevels<2>) + 2), t->counters)
+    if constexpr (sizeof(T) == 8) {
+      if (t->counters_on) NB_OT_ISA(ot_force_isa_kernel, true);
+      else NB_OT_ISA(ot_force_isa_kernel, false);
+    } else {
+      if (t->counters_on) NB_OT_ISA(ot_force_isa_f32_kernel, true);
+      else NB_OT_ISA(ot_force_isa_f32_kernel, false);
     }
+#undef NB_OT_ISA
   } else if (t->counters_on) NB_OT_LAUNCH(true);
   else NB_OT_LAUNCH(false);
 #undef NB_OT_LAUNCH

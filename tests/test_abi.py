@@ -3,6 +3,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -113,6 +114,38 @@ def test_smem_pipeline_registers_untouched_in_flight(nb):
     loads, problems = mod.check(nb.LIB_PATH)
     assert loads >= 64, f"only {loads} s_load_dwordx16 found: K1's scalar-stream kernels are missing from the disassembly"
     assert not problems, "\n".join(problems[:10])
+
+
+def test_no_unpadded_isa_hazards_in_the_code_object(nb):
+    """hipcc pads the data hazards of its own instructions, not those inside or at the edge of an asm block (round 3: an asm
+    v_readfirstlane_b32 directly behind the compiler's v_mov of its source read the register's previous content in three
+    octree instantiations — csrc/to_sgpr.hpp).  tools/check_isa_hazards.py walks every kernel of the shipped code object along
+    its control flow and applies the gfx940-class wait-state rules; built without the pads it flags exactly the three
+    instantiations that were wrong on the hardware, and nothing else."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("check_isa_hazards", os.path.join(ROOT, "tools", "check_isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    total, lanes, problems = mod.check(nb.LIB_PATH)
+    assert total > 50000 and lanes > 100, (total, lanes)   # the disassembly really is the library's
+    assert not problems, "\n".join(problems[:10])
+    # the rules themselves: a producer directly in front of its consumer is flagged, the padded pair is not
+    def run(lines):
+        code = [mod.Ins(4 * k, t, None) for k, t in enumerate(lines)]
+        index = {c.addr: k for k, c in enumerate(code)}
+        return [r for i in range(len(code)) for r, *_ in mod.violations_from(code, index, i)]
+    assert run(["v_mov_b32_e32 v9, s22", "v_readfirstlane_b32 s36, v9"]) == ["A"]
+    assert run(["v_mov_b32_e32 v9, s22", "s_nop 0", "v_readfirstlane_b32 s36, v9"]) == []
+    assert run(["v_cmp_gt_f32_e32 vcc, s0, v12", "s_nop 0", "v_cndmask_b32_e32 v12, v12, v13, vcc"]) == ["D"]
+    assert run(["v_cmp_gt_f32_e32 vcc, s0, v12", "s_nop 1", "v_cndmask_b32_e32 v12, v12, v13, vcc"]) == []
+    assert run(["v_rsq_f64_e32 v[2:3], v[4:5]", "v_mul_f64 v[6:7], v[2:3], v[2:3]"]) == ["C"]
+    assert run(["v_readlane_b32 s5, v1, s2", "s_nop 0", "v_cmp_gt_u32_e32 vcc, s5, v3"]) == ["D"]
+    assert run(["v_cmp_eq_u32_e64 s[4:5], v1, v2", "v_nop", "v_nop", "global_load_dword v3, v4, s[4:5]"]) == ["G"]
+    assert run(["v_cmpx_eq_u32_e64 s[4:5], v1, v2", "v_nop", "v_readfirstlane_b32 s7, v9"]) == ["H"]
+    assert run(["v_div_scale_f32 v15, vcc, s22, v12, s22", "v_nop", "v_nop", "v_div_fmas_f32 v13, v13, v14, v16"]) == ["F"]
 
 
 def test_shipped_binaries_read_no_environment(nb):

@@ -178,10 +178,16 @@ void nbody_octree_destroy(nbody_octree* t);
 /* Scheduling form of the walk: 0 = auto, 1 = the compiler-scheduled kernel, 2 = the visit round written as ISA (fails where that
  * form does not exist).  Same tests, same arithmetic, same order: bitwise identical accelerations and counters. */
 int  nbody_octree_set_walk(nbody_octree* t, int mode);
-/* How the breadth-first build and the multipole pass are launched: 1 = one launch per tree level (21 + 21 in 3D); 0 = auto:
- * one launch per level the tree used at the last nbody_octree_info (+ 2) and ONE launch for all deeper levels, which walks
- * them behind a grid barrier (at most one block per compute unit) and normally finds them empty; 2 = every level behind
- * the grid barrier (measured slower on MI355X, kept as a cross-check).  Same tree, same monopoles bit for bit. */
+/* How the tree is built from the sorted path keys and how the multipole pass is launched:
+ *   0 = auto (3);
+ *   3 = one pass: every cell follows from the common key prefixes of neighbouring bodies, so all cells are numbered by one prefix
+ *       sum and built at once (4 launches whatever the depth), and the multipoles take two (rank chunks, then the cells that span
+ *       chunk boundaries);
+ *   1 = breadth-first, one launch per tree level for the build and one for the multipoles (21 + 21 in 3D);
+ *   4 = as 1 for the levels the tree used at the last nbody_octree_info (+ 2), ONE launch behind a grid barrier for the rest;
+ *   2 = every level behind the grid barrier (measured slower on MI355X).
+ * 1, 2 and 4 number the sibling groups breadth-first, 3 in pre-order; the cells, their monopoles, the tree size and every
+ * force and counter the walk produces are the same bit for bit. */
 int  nbody_octree_set_build(nbody_octree* t, int mode);
 /* Visit rounds one body's walk may make before it is abandoned and nbody_octree_info reports it (never spin on a damaged
  * tree).  0 = the default: the node pool size, which no walk of a well-formed tree reaches. */

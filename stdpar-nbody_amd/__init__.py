@@ -285,7 +285,8 @@ class Octree:
         _check(lib().nbody_octree_create_on(C.byref(self.h), dtype, dim, C.c_uint32(n), device))
 
     def set_build(self, mode):
-        """0 auto, 1 one launch per tree level, 2 all levels in one launch (grid barrier); bitwise identical trees."""
+        """0 auto (= 3), 1 one launch per tree level, 2 all levels behind a grid barrier, 3 one pass over the sorted keys, 4 per-level
+        for the levels of the last info + one launch for the rest.  Same cells, monopoles, forces and counters bit for bit."""
         _check(lib().nbody_octree_set_build(self.h, mode))
 
     def set_step_budget(self, steps):

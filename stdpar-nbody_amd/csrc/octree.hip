@@ -42,8 +42,11 @@ constexpr int kOtDeepFrames = kOtDeepLevels + 7 * 28 + 12;
 template <int D>
 constexpr int kMaxLevels = D == 3 ? 21 : 32;
 
-struct ot_cell {  // an internal cell waiting to be split: its node index and its range of sorted bodies
-  uint32_t node, start, end;
+// Per-level build: an internal cell waiting to be split — its node index, its range of sorted bodies and its rank (= sibling group
+// number).  One-pass build: entry r describes the cell of rank r — node index, `start` = its level, `end` = one past the last rank
+// of its subtree.
+struct ot_cell {
+  uint32_t node, start, end, rank;
 };
 
 // One tree node: monopole (src/octree.h:55-56 `m`), first child (src/octree.h:52) and depth.  The side of a node's cell
@@ -288,7 +291,7 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
     r.lvl  = 0;
     r.fc   = kOtEmpty;
     if (n >= 2) {       // the root holds >= 2 bodies: it is the first cell to split
-      cells[0]     = ot_cell{0u, 0u, n};
+      cells[0]     = ot_cell{0u, 0u, n, 0u};
       lvl_count[0] = 1;
     } else {  // a single body stays in the root (src/octree.h:140-145)
 #pragma unroll
@@ -412,7 +415,7 @@ __device__ __forceinline__ void ot_build_level_body(int level, uint32_t vblock, 
   if (split) {
     const uint32_t pos =
         base + count + block_first + wave_first[wave] + uint32_t(__builtin_popcountll(voters & ((1ull << lane) - 1ull)));
-    if (pos < max_cells) cells[pos] = ot_cell{ci, lo, end};
+    if (pos < max_cells) cells[pos] = ot_cell{ci, lo, end, pos};
     else atomicOr(flags, kFlagCapacity);
   }
 }
@@ -493,21 +496,26 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
                                                            const T* __restrict__ m,
                                                            const T* __restrict__ x, const T* __restrict__ root,
                                                            ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                           const ot_cell* __restrict__ tops,
                                                            uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ flags,
                                                            uint32_t capacity) {
 #pragma clang fp contract(off)
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
-  uint32_t base = 0;  // cells of the levels above = position of the first cell of depth ML
+  uint32_t base = 0;  // cells of the levels above = position of the first cell of depth ML in the per-level build's list
   for (int j = 0; j < ML; ++j) base += lvl_count[j];
-  const uint32_t count = lvl_count[ML], regular = base + count;
+  // the cells of depth ML: the per-level build's list continues with them (tops == nullptr); the one-pass build appended them to
+  // a list of their own, whose length is its cursor (a top whose parent ran out of node pool is counted but not listed)
+  const uint32_t regular = base + lvl_count[ML];
+  const uint32_t count   = tops ? lvl_count[ML + 5] : lvl_count[ML];
+  if (!tops) tops = cells + base;
   struct frame {
     uint32_t node, s, e;
     uint32_t rank_level;  // level | done << 31 ; rank of a regular (depth ML) cell is implied by its position
   };
   frame stack[kOtDeepFrames];
   for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
-    const ot_cell top = cells[base + k];
+    const ot_cell top = tops[k];
     int sp            = 0;
     stack[sp++]       = frame{top.node, top.start, top.end, uint32_t(ML)};
     bool failed       = false;
@@ -539,7 +547,7 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
         --sp;
         continue;
       }
-      const uint32_t rank = f.node == top.node ? base + k : regular + atomicAdd(&lvl_count[ML + 1], 1u);
+      const uint32_t rank = f.node == top.node ? top.rank : regular + atomicAdd(&lvl_count[ML + 1], 1u);
       const uint32_t fc   = 1u + rank * NCH;
       if (fc + NCH > capacity) {
         atomicOr(flags, kFlagCapacity);
@@ -666,6 +674,643 @@ __global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T,
     base -= count;
     for (uint32_t k = blockIdx.x * kOB + threadIdx.x; k < count; k += gridDim.x * kOB) ot_multipole_cell<T, D>(tree, cells[base + k].node);
     if (l > lowest_level && !ot_grid_barrier(counter, epoch, flags)) break;
+  }
+}
+
+// ---- one-pass build (nbody_octree_set_build 3 / auto) -----------------------------------------------------------------------
+// The per-level build above is a chain of dependent launches (a level's cell list is the product of the level before), and a
+// dependent launch costs >= 4.7 us on this chip whatever it does: 16 + 16 of them are a third of the octree step at the
+// reference's benchmark size (N = 10^5, profiles/r03/small_trees_kernel_stats.txt); a grid barrier is no cheaper (~12 us).
+// The sorted keys already hold the whole tree, though.  With l_i = the number of leading key digits bodies i-1 and i share
+// (l_0 = l_n = -1), a cell of level d over the sorted range [s, e) exists exactly when s's left boundary has l_s < d and
+// the range holds >= 2 bodies, i.e. l_(s+1) >= d: position i starts the cells of levels l_i + 1 ... l_(i+1), and nothing else
+// does.  An exclusive prefix sum P of max(0, l_(i+1) - l_i) over the positions therefore NUMBERS every cell — rank(i, d) =
+// P[i] + d - l_i - 1, pre-order: a cell's subtree is the rank interval [rank, P[e]) — and every cell can be built on its own:
+// its end by a search for the first key with another d-digit prefix, its 2^D child ranges by the digit searches of the per-level
+// build, and the group number of a child cell from the same formula — no cell waits for its parent.  Launches: ot_lcp_kernel
+// (boundaries, block-local prefix, level histogram), ot_lcp_finish_kernel (one block: block bases, level counts for
+// nbody_octree_info), ot_build_lcp_kernel, then ot_build_deep_kernel as before for cells below the key depth.
+// The multipoles need children before parents.  In rank order every subtree is an interval, so a block that owns a chunk of ranks
+// can finish, level by level with block barriers only, every cell whose subtree ends inside its chunk
+// (ot_multipole_chunks_kernel); the cells it cannot — the <= kMaxLevels ancestors of each chunk boundary — are listed and
+// finished by ONE block afterwards (ot_multipole_crown_kernel).  Same children, same order, same arithmetic as
+// ot_multipole_cell: the tree is the per-level build's up to the numbering of the sibling groups, and the walk (which pushes
+// children in slot order) produces bit-identical forces and counters (tests/test_gpu_octree.py::test_octree_build_forms).
+constexpr int kLcpB = 1024;   // positions per block of ot_lcp_kernel
+constexpr int kLcpBuildB = 256;  // ot_build_lcp_kernel: lane groups are independent, small blocks give their slots back early
+constexpr int kMpChunk = 512;  // ot_multipole_chunks_kernel: ranks (= threads) per block (512: a double 3D cell keeps 2^D x 4 values in registers)
+constexpr int kMpCrown = 512;  // ot_multipole_crown_kernel: threads, and cells it finishes out of registers and LDS
+
+template <int D>
+__device__ __forceinline__ int ot_common_levels(uint64_t a, uint64_t b) {
+  const uint64_t x = a ^ b;
+  if (x == 0) return kMaxLevels<D>;
+  return (__builtin_clzll(x) - (64 - D * kMaxLevels<D>)) / D;
+}
+
+// positions 0 ... n (n + 1 of them: P[n] = the number of cells)
+template <int D>
+__global__ __launch_bounds__(kLcpB) void ot_lcp_kernel(const uint64_t* __restrict__ skeys, uint32_t n, int8_t* __restrict__ lv,
+                                                       uint32_t* __restrict__ plocal, uint32_t* __restrict__ bsum,
+                                                       uint32_t* __restrict__ bhist) {
+  constexpr int ML = kMaxLevels<D>;
+  __shared__ uint32_t hist[ML + 1];
+  __shared__ uint32_t wsum[kLcpB / 64];
+  if (threadIdx.x <= uint32_t(ML)) hist[threadIdx.x] = 0;
+  __syncthreads();
+  const uint32_t i = blockIdx.x * kLcpB + threadIdx.x;
+  int li = -1, ln = -1;
+  if (i < n) {
+    const uint64_t k = skeys[i];
+    if (i > 0) li = ot_common_levels<D>(skeys[i - 1], k);
+    if (i + 1 < n) ln = ot_common_levels<D>(k, skeys[i + 1]);
+  }
+  if (i <= n) lv[i] = int8_t(li);
+  const uint32_t cnt = ln > li ? uint32_t(ln - li) : 0u;
+  for (int d = li + 1; d <= ln; ++d) atomicAdd(&hist[d], 1u);
+  // block-wide exclusive prefix of cnt
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t inc = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t up = __shfl_up(inc, off, 64);
+    if (lane >= uint32_t(off)) inc += up;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  uint32_t before = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kLcpB / 64; ++w) {
+    const uint32_t v = wsum[w];
+    if (uint32_t(w) < wave) before += v;
+    total += v;
+  }
+  if (i <= n) plocal[i] = before + inc - cnt;
+  if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+  if (threadIdx.x <= uint32_t(ML)) bhist[blockIdx.x * (ML + 1) + threadIdx.x] = hist[threadIdx.x];
+}
+
+// one block: exclusive scan of the block sums (in place), the level counts, the counters of the later kernels, the root of n = 1
+template <typename T, int D>
+__global__ __launch_bounds__(1024) void ot_lcp_finish_kernel(uint32_t n, uint32_t nblk, uint32_t* __restrict__ bsum,
+                                                             const uint32_t* __restrict__ bhist, const T* __restrict__ m,
+                                                             const T* __restrict__ x, ot_tree<T, D> tree,
+                                                             uint32_t* __restrict__ lvl_count) {
+  constexpr int ML = kMaxLevels<D>;
+  __shared__ uint32_t hist[ML + 1];
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x <= uint32_t(ML)) hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t k = threadIdx.x; k < nblk * uint32_t(ML + 1); k += 1024) {
+    const uint32_t v = bhist[k];
+    if (v) atomicAdd(&hist[k % uint32_t(ML + 1)], v);
+  }
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  for (uint32_t b0 = 0; b0 < nblk; b0 += 1024) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nblk ? bsum[b] : 0u;
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(inc, off, 64);
+      if (lane >= uint32_t(off)) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = carry_s, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const uint32_t q = wsum[w];
+      if (uint32_t(w) < wave) before += q;
+      total += q;
+    }
+    if (b < nblk) bsum[b] = before + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s += total;
+    __syncthreads();
+  }
+  if (threadIdx.x <= uint32_t(ML)) lvl_count[threadIdx.x] = hist[threadIdx.x];  // [ML]: cells at the key depth (ot_build_deep_kernel)
+  if (threadIdx.x == 0) {
+    lvl_count[ML + 1] = 0;  // groups of the deep build
+    lvl_count[ML + 5] = 0;  // its list of depth-ML cells
+    lvl_count[ML + 6] = 0;  // cells left to ot_multipole_crown_kernel
+    if (n < 2) {            // a single body stays in the root (src/octree.h:140-145)
+      ot_node<T> r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r.p[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) r.p[k] = x[k];
+      r.m   = m[0];
+      r.lvl = 0;
+      r.fc  = kOtBody;
+      tree.put(0, r);
+    }
+  }
+}
+
+// First position in [a, b) of the sorted keys whose key satisfies a monotone predicate (b if none), probing 7 positions per round
+// trip: the searches of the big cells are chains of dependent loads, ~1.5 us each.
+template <typename P>
+__device__ __forceinline__ uint32_t ot_first_true(const uint64_t* __restrict__ skeys, uint32_t a, uint32_t b, P pred) {
+  while (b - a > 8) {
+    const uint32_t step = (b - a) / 8;
+    bool t[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) t[j] = pred(skeys[a + step * uint32_t(j + 1)]);
+    uint32_t na = a, nb = b;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 7; ++j) {
+      if (!found) {
+        if (t[j]) {
+          nb    = a + step * uint32_t(j + 1);
+          found = true;
+        } else {
+          na = a + step * uint32_t(j + 1) + 1;
+        }
+      }
+    }
+    a = na;
+    b = nb;
+  }
+  bool t[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = a + uint32_t(j) < b ? pred(skeys[a + uint32_t(j)]) : true;
+  uint32_t falses = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) falses += !t[j] && falses == uint32_t(j);
+  return a + falses;
+}
+
+// The levels whose cells get lane groups of their own (extra blocks of ot_build_lcp_kernel).  A position that starts a top-level
+// cell usually starts the nested first children below it as well — position 0 starts one cell per level down to the first split —
+// and each of those is a big cell with its searches: in the position loop that was ONE lane group working for 40 us while the
+// average wave takes 6 (N = 10^5).  1 + 2^D + ... cells: 585 in 3D, 341 in 2D.
+template <int D>
+constexpr int kTopLevels = D == 3 ? 4 : 5;
+template <int D>
+constexpr uint32_t kTopCells = D == 3 ? 585u : 341u;
+
+template <typename T, int D>
+struct ot_lcp_args {
+  const uint64_t* skeys;
+  const uint32_t* sidx;
+  uint32_t n;
+  const int8_t* lv;
+  const uint32_t* plocal;
+  const uint32_t* bbase;
+  const T* m;
+  const T* x;
+  ot_tree<T, D> tree;
+  ot_cell* cells;
+  ot_cell* tops;
+  uint32_t* lvl_count;
+  uint32_t* flags;
+  uint32_t capacity, max_cells;
+};
+
+// One cell — level d, starting at sorted position i, whose left boundary shares li < d key digits — by its 2^D lanes: the end of its
+// range (`e`, or 0 = not known yet), its child ranges, its child records, its entry.  false: the node pool is exhausted.
+template <typename T, int D>
+__device__ __forceinline__ bool ot_lcp_cell(const ot_lcp_args<T, D>& g, uint32_t i, int d, int li, uint32_t c, uint32_t e) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  const uint64_t* __restrict__ skeys = g.skeys;
+  const uint32_t n = g.n;
+  auto rank_at = [&](uint32_t pos, int level, int l_pos) { return g.bbase[pos / kLcpB] + g.plocal[pos] + uint32_t(level - l_pos - 1); };
+  auto fits    = [&](uint32_t rank) { return rank < g.max_cells && 1u + rank * NCH + NCH <= g.capacity; };
+  const uint32_t r = rank_at(i, d, li);
+  if (!fits(r)) {  // its parent left it an empty leaf; reported by nbody_octree_info
+    if (c == 0) atomicOr(g.flags, kFlagCapacity);
+    return false;
+  }
+  const uint32_t fc = 1u + r * NCH;
+  // The cell's end (the first position whose key leaves the d-digit prefix) and its 2^D child ranges.  Most cells hold a
+  // handful of bodies: the 2^D lanes read 2^D keys per round and count, so such a cell costs ONE round trip instead of a
+  // chain of ~12 dependent probes.  Cells that have not ended after kScanRounds rounds are searched.
+  constexpr int kScanRounds = 4;
+  const int psh       = d > 0 ? D * (ML - d) : 0;
+  const uint64_t pref = d > 0 ? skeys[i] >> psh : 0;
+  const int shift     = D * (ML - 1 - d);
+  uint32_t lo = i, end = i;
+  bool searched = e != 0;
+  if (!searched) {
+    uint32_t below = 0, upto = 0, size = 0;
+    bool ended = false;
+#pragma unroll 1
+    for (int round = 0; round < kScanRounds && !ended; ++round) {
+      const uint32_t pos = i + uint32_t(round) * NCH + c;
+      uint32_t digit     = NCH;  // outside the cell
+      if (pos < n) {
+        const uint64_t k = skeys[pos];
+        if (d == 0 || (k >> psh) == pref) digit = uint32_t(k >> shift) & (NCH - 1);
+      }
+      uint32_t inside = 0;
+#pragma unroll
+      for (uint32_t j = 0; j < NCH; ++j) {  // sorted keys: the lanes inside the cell are a prefix of the lane group
+        const uint32_t dj = __shfl(digit, int(j), NCH);
+        below += dj < c;
+        upto += dj <= c;
+        inside += dj < NCH;
+      }
+      size += inside;
+      ended = inside < NCH;
+    }
+    if (ended) {
+      e   = i + size;
+      lo  = i + below;
+      end = i + upto;
+    } else {
+      searched = true;
+      e        = n;
+      if (d > 0) {
+        uint32_t in_e = i + kScanRounds * NCH - 1, bound = kScanRounds * NCH * 8;  // key[in_e] is inside
+        while (i + bound < n && (skeys[i + bound] >> psh) == pref) {
+          in_e = i + bound;
+          bound *= 8;
+        }
+        const uint32_t out_e = i + bound < n ? i + bound : n;
+        e = ot_first_true(skeys, in_e + 1, out_e, [&](uint64_t k) { return (k >> psh) != pref; });
+      }
+    }
+  }
+  if (searched) {
+    lo = c == 0 ? i : ot_first_true(skeys, i, e, [&](uint64_t k) { return (uint32_t(k >> shift) & (NCH - 1)) >= c; });
+    const uint32_t up = __shfl_down(lo, 1, NCH);
+    end               = c + 1 < NCH ? up : e;
+  }
+  const uint32_t ci = fc + c;
+  ot_node<T> rec;
+#pragma unroll
+  for (int q = 0; q < 3; ++q) rec.p[q] = T(0);
+  rec.m   = T(0);
+  rec.lvl = uint32_t(d) + 1u;
+  rec.fc  = kOtEmpty;
+  if (end - lo == 1) {
+    const uint64_t b = g.sidx[lo];
+#pragma unroll
+    for (int q = 0; q < D; ++q) rec.p[q] = g.x[b * D + q];
+    rec.m  = g.m[b];
+    rec.fc = kOtBody;
+  } else if (end - lo >= 2) {  // a cell of level d + 1 starting at lo: its left boundary shares l_i (lo == i) or exactly d digits
+    const uint32_t rc = rank_at(lo, d + 1, lo == i ? li : d);
+    if (d + 1 == ML) {         // below the key depth: ot_build_deep_kernel splits it (and sets its fc)
+      if (fits(rc)) {
+        const uint32_t k = atomicAdd(&g.lvl_count[ML + 5], 1u);
+        g.tops[k]        = ot_cell{ci, lo, end, rc};
+        g.cells[rc]      = ot_cell{ci, uint32_t(ML), rc + 1u, rc};
+      } else {
+        atomicOr(g.flags, kFlagCapacity);
+      }
+    } else if (fits(rc)) {
+      rec.fc           = 1u + rc * NCH;
+      g.cells[rc].node = ci;  // (the cell itself writes the other fields)
+    } else {
+      atomicOr(g.flags, kFlagCapacity);
+    }
+  }
+  g.tree.put(ci, rec);
+  if (c == 0) {
+    g.cells[r].start = uint32_t(d);
+    g.cells[r].end   = g.bbase[e / kLcpB] + g.plocal[e];  // P[e]: one past its subtree
+    g.cells[r].rank  = r;
+    if (d == 0) {  // the root cell: node 0 is a record of its own
+      ot_node<T> root;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) root.p[q] = T(0);
+      root.m   = T(0);
+      root.lvl = 0;
+      root.fc  = fc;
+      g.tree.put(0, root);
+      g.cells[0].node = 0;
+    }
+  }
+  return true;
+}
+
+// Blocks [0, position_blocks): 2^D lanes per sorted position build the cells below the top levels that start there, shallowest
+// first.  The blocks behind them: 2^D lanes per possible top-level cell (level, prefix) find its range in the sorted keys and,
+// if it holds >= 2 bodies, build it.
+template <typename T, int D>
+__global__ __launch_bounds__(kLcpBuildB) void ot_build_lcp_kernel(ot_lcp_args<T, D> g, uint32_t position_blocks) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  constexpr int TOP      = kTopLevels<D>;
+  const uint32_t c = threadIdx.x % NCH;
+  if (blockIdx.x >= position_blocks) {
+    uint32_t q = ((blockIdx.x - position_blocks) * kLcpBuildB + threadIdx.x) / NCH;  // which top cell
+    if (q >= kTopCells<D>) return;
+    int d = 0;
+    for (uint32_t width = 1; q >= width; width *= NCH) {  // level d has 2^(D d) prefixes
+      q -= width;
+      ++d;
+    }
+    uint32_t s = 0, e = g.n;
+    if (d > 0) {
+      const int psh = D * (ML - d);
+      s = ot_first_true(g.skeys, 0u, g.n, [&](uint64_t k) { return (k >> psh) >= uint64_t(q); });
+      e = ot_first_true(g.skeys, s, g.n, [&](uint64_t k) { return (k >> psh) > uint64_t(q); });
+    }
+    if (e - s >= 2) ot_lcp_cell<T, D>(g, s, d, int(g.lv[s]), c, e);
+    return;
+  }
+  const uint32_t i = (blockIdx.x * kLcpBuildB + threadIdx.x) / NCH;
+  if (i >= g.n) return;  // (whole lane groups)
+  const int li = g.lv[i], ln = g.lv[i + 1];
+  for (int d = li + 1 > TOP ? li + 1 : TOP; d <= ln && d < ML; ++d)
+    if (!ot_lcp_cell<T, D>(g, i, d, li, c, 0u)) break;  // (deeper cells have higher ranks)
+}
+
+template <typename T, int D>
+__device__ __forceinline__ uint32_t ot_lcp_total(const uint32_t* lvl_count) {
+  uint32_t total = 0;
+#pragma unroll
+  for (int l = 0; l <= kMaxLevels<D>; ++l) total += lvl_count[l];
+  return total;
+}
+
+// A cell's monopole from its 2^D child records held in registers, children that are cells of THIS block's work taken from LDS
+// instead (`slot[c]` != none).  Same order, same arithmetic as ot_multipole_cell.
+constexpr uint32_t kMpNone = 0xffffffffu, kMpLater = 0x80000000u;
+
+template <typename T, int D>
+__device__ __forceinline__ void ot_multipole_from_registers(const T (&cm)[1u << D], const T (&cp)[1u << D][D], const uint32_t (&slot)[1u << D],
+                                                            const T (*sm)[4], T& mass, T (&com)[D]) {
+#pragma clang fp contract(off)
+  constexpr uint32_t NCH = 1u << D;
+  T xx[D];
+  mass = T(0);
+#pragma unroll
+  for (int q = 0; q < D; ++q) xx[q] = T(0);
+#pragma unroll
+  for (uint32_t c = 0; c < NCH; ++c) {
+    T mc = cm[c], pc[D];
+#pragma unroll
+    for (int q = 0; q < D; ++q) pc[q] = cp[c][q];
+    if (slot[c] != kMpNone) {
+      mc = sm[slot[c]][0];
+#pragma unroll
+      for (int q = 0; q < D; ++q) pc[q] = sm[slot[c]][1 + q];
+    }
+    mass += mc;
+#pragma unroll
+    for (int q = 0; q < D; ++q) xx[q] += mc * pc[q];
+  }
+#pragma unroll
+  for (int q = 0; q < D; ++q) com[q] = xx[q] / mass;
+}
+
+// Large trees (more chunks than the crown kernel finishes out of LDS): one launch per level over all ranks.  21 launches are then
+// a small part of the step, and nothing grows with the number of chunk boundaries.
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_multipole_ranks_level_kernel(int level, ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                                       const uint32_t* __restrict__ lvl_count, uint32_t capacity,
+                                                                       uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  const uint32_t r = blockIdx.x * kOB + threadIdx.x;
+  if (r >= total || 1u + r * NCH + NCH > capacity) return;
+  const ot_cell cl = cells[r];
+  if (int(cl.start) == level) ot_multipole_cell<T, D>(tree, cl.node);
+}
+
+// A block barrier that waits for the LDS traffic only.  __syncthreads() also waits for every global store in flight (its
+// fence covers all address spaces), and a store's round trip is ~2 us here: with one per level that was the whole level loop.
+// Nothing in these kernels reads back what it stored to global memory.
+__device__ __forceinline__ void ot_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// One rank per thread.  Everything a cell needs from memory — its entry and its 2^D child records — is loaded BEFORE the level loop
+// and side by side (the loop would otherwise be a chain of dependent round trips per level: 3.7 us each, measured); inside the
+// loop the only values that are not there yet, the monopoles of child cells, come from LDS, where the block keeps what it has
+// finished.  The cells left to the crown kernel are the ancestors of the next chunk's first cell that lie in this chunk: at
+// most one per level, so they go to the fixed slot (block, level) of `later` and a bit of the block's mask — no counter.
+template <typename T, int D>
+__global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T, D> tree, ot_cell* __restrict__ cells,
+                                                                      const uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ later,
+                                                                      uint32_t* __restrict__ later_mask, uint32_t capacity,
+                                                                      uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  __shared__ T sm[kMpChunk][4];
+  __shared__ int lvl_hi, lvl_lo;
+  __shared__ uint32_t mask_s;
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  const uint32_t first = blockIdx.x * kMpChunk;
+  if (first >= total) return;
+  const uint32_t last = first + kMpChunk < total ? first + kMpChunk : total;
+  if (threadIdx.x == 0) {
+    lvl_hi = -1;
+    lvl_lo = ML;
+    mask_s = 0;
+  }
+  ot_lds_barrier();
+  const uint32_t r = first + threadIdx.x;
+  const bool have  = r < last && 1u + r * NCH + NCH <= capacity;
+  int level = -1;  // -1: nothing to do for this rank
+  bool wait = false;
+  uint32_t node = 0;
+  T cm[NCH], cp[NCH][D];
+  uint32_t cfc[NCH], slot[NCH];
+  if (have) {
+    const ot_cell cl = cells[r];
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; ++c) {  // (does not depend on the entry: all 2^D records and the entry are in flight together)
+      const ot_node<T> ch = tree.groups[r].load(c);
+      cm[c]  = ch.m;
+      cfc[c] = ch.fc;
+#pragma unroll
+      for (int q = 0; q < D; ++q) cp[c][q] = ch.p[q];
+    }
+    if (int(cl.start) < ML) {  // (cells at the key depth were finished by ot_build_deep_kernel)
+      node  = cl.node;
+      level = int(cl.start);
+      wait  = cl.end > last;  // part of its subtree belongs to a later block
+#pragma unroll
+      for (uint32_t c = 0; c < NCH; ++c)  // a child that is a cell above the key depth is finished in this kernel: by this block,
+        slot[c] = cfc[c] < kOtBody && level + 1 < ML ? cfc[c] - first : kMpNone;  // if this cell is (stored fc = group = rank)
+      if (wait) {
+        atomicOr(&mask_s, 1u << level);
+        later[blockIdx.x * uint32_t(ML) + uint32_t(level)] = r;
+        cells[r].rank = kMpLater | (blockIdx.x * uint32_t(ML) + uint32_t(level));
+      }
+    }
+  }
+  {  // the levels this block has to walk (one LDS atomic per wave: 2 x 512 same-address ones were 7 us)
+    int wmax = level >= 0 && !wait ? level : -1, wmin = level >= 0 && !wait ? level : ML;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int a = __shfl_xor(wmax, off, 64), b = __shfl_xor(wmin, off, 64);
+      wmax = a > wmax ? a : wmax;
+      wmin = b < wmin ? b : wmin;
+    }
+    if ((threadIdx.x & 63u) == 0 && wmax >= 0) {
+      atomicMax(&lvl_hi, wmax);
+      atomicMin(&lvl_lo, wmin);
+    }
+  }
+  ot_lds_barrier();
+  const int hi = lvl_hi, lo = lvl_lo;
+  if (threadIdx.x == 0) later_mask[blockIdx.x] = mask_s;
+  for (int l = hi; l >= lo; --l) {
+    if (level == l && !wait) {
+      T mass, com[D];
+      ot_multipole_from_registers<T, D>(cm, cp, slot, sm, mass, com);
+      ot_node<T> pn;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pn.p[q] = T(0);
+#pragma unroll
+      for (int q = 0; q < D; ++q) pn.p[q] = com[q];
+      pn.m   = mass;
+      pn.lvl = uint32_t(level);
+      pn.fc  = 1u + r * NCH;
+      tree.put(node, pn);
+      sm[threadIdx.x][0] = mass;
+#pragma unroll
+      for (int q = 0; q < D; ++q) sm[threadIdx.x][1 + q] = com[q];
+    }
+    ot_lds_barrier();
+  }
+}
+
+// One block: the cells whose subtrees span chunk boundaries, deepest level first.  They sit in the slots (chunk, level) that the
+// chunks' masks name.  Up to kMpCrown of them in up to kMpCrown chunks: compacted, one per thread, the same way as above.
+// More: level by level over the chunks, children read from memory.
+template <typename T, int D>
+__global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                                  const uint32_t* __restrict__ lvl_count,
+                                                                  const uint32_t* __restrict__ later,
+                                                                  const uint32_t* __restrict__ later_mask, uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  __shared__ T sm[kMpCrown][4];
+  __shared__ uint32_t base[kMpCrown + 1];  // compact position of a chunk's first waiting cell
+  __shared__ uint32_t maskl[kMpCrown];     // the chunks' masks
+  __shared__ uint32_t wsum[kMpCrown / 64];
+  __shared__ int lvl_hi;
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  const uint32_t nchunks = (total + kMpChunk - 1) / kMpChunk;
+  if (nchunks <= 1) return;  // (a single chunk leaves nothing)
+  if (threadIdx.x == 0) lvl_hi = -1;
+  bool fast = nchunks <= uint32_t(kMpCrown);
+  uint32_t count = 0, mymask = 0;
+  if (fast) {  // exclusive prefix of the chunks' waiting cells
+    mymask = threadIdx.x < nchunks ? later_mask[threadIdx.x] : 0u;
+    const uint32_t v    = uint32_t(__builtin_popcount(mymask));
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t inc        = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(inc, off, 64);
+      if (lane >= uint32_t(off)) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    ot_lds_barrier();
+    uint32_t before = 0;
+#pragma unroll
+    for (int w = 0; w < kMpCrown / 64; ++w) {
+      const uint32_t q = wsum[w];
+      if (uint32_t(w) < wave) before += q;
+      count += q;
+    }
+    base[threadIdx.x]  = before + inc - v;
+    maskl[threadIdx.x] = mymask;
+    if (threadIdx.x == 0) base[kMpCrown] = count;
+    fast = count <= uint32_t(kMpCrown);
+  }
+  ot_lds_barrier();
+  if (fast) {
+    int level = -1;
+    uint32_t node = 0, r = 0;
+    T cm[NCH], cp[NCH][D];
+    uint32_t slot[NCH];
+    if (threadIdx.x < count) {
+      uint32_t b = 0, hi_b = nchunks;  // the chunk whose cells include compact position threadIdx.x: last b with base[b] <= it
+      while (hi_b - b > 1) {
+        const uint32_t mid = b + (hi_b - b) / 2;
+        if (base[mid] <= threadIdx.x) b = mid;
+        else hi_b = mid;
+      }
+      uint32_t m = maskl[b];
+      for (uint32_t skip = threadIdx.x - base[b]; skip > 0; --skip) m &= m - 1u;  // its (skip+1)-th set bit
+      const uint32_t lvl_bit = uint32_t(__builtin_ctz(m));
+      r                      = later[b * uint32_t(ML) + lvl_bit];
+      const ot_cell cl       = cells[r];
+      node                   = cl.node;
+      level                  = int(cl.start);
+      uint32_t crank[NCH];
+#pragma unroll
+      for (uint32_t c = 0; c < NCH; ++c) {
+        const ot_node<T> ch = tree.groups[r].load(c);
+        cm[c] = ch.m;
+#pragma unroll
+        for (int q = 0; q < D; ++q) cp[c][q] = ch.p[q];
+        crank[c] = ch.fc < kOtBody && level + 1 < ML ? ch.fc : kMpNone;
+      }
+#pragma unroll
+      for (uint32_t c = 0; c < NCH; ++c) {  // a child cell is either finished (by a chunk) or waiting here too
+        slot[c] = kMpNone;
+        if (crank[c] != kMpNone) {
+          const uint32_t mark = cells[crank[c]].rank;
+          if (mark & kMpLater) {
+            const uint32_t sl = mark & ~kMpLater, cb = sl / uint32_t(ML), cl_bit = sl % uint32_t(ML);
+            slot[c] = base[cb] + uint32_t(__builtin_popcount(maskl[cb] & ((1u << cl_bit) - 1u)));
+          }
+        }
+      }
+      atomicMax(&lvl_hi, level);
+    }
+    ot_lds_barrier();
+    for (int l = lvl_hi; l >= 0; --l) {
+      if (level == l) {
+        T mass, com[D];
+        ot_multipole_from_registers<T, D>(cm, cp, slot, sm, mass, com);
+        ot_node<T> pn;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) pn.p[q] = T(0);
+#pragma unroll
+        for (int q = 0; q < D; ++q) pn.p[q] = com[q];
+        pn.m   = mass;
+        pn.lvl = uint32_t(level);
+        pn.fc  = 1u + r * NCH;
+        tree.put(node, pn);
+        sm[threadIdx.x][0] = mass;
+#pragma unroll
+        for (int q = 0; q < D; ++q) sm[threadIdx.x][1 + q] = com[q];
+      }
+      ot_lds_barrier();
+    }
+    return;
+  }
+  // many chunks: each level's waiting cells straight from the slots (a thread keeps the masks of its first chunks in registers)
+  constexpr int PER = 8;
+  uint32_t masks[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const uint32_t b = threadIdx.x + uint32_t(j) * uint32_t(kMpCrown);
+    masks[j]         = b < nchunks ? later_mask[b] : 0u;
+    if (masks[j]) atomicMax(&lvl_hi, 31 - __builtin_clz(masks[j]));
+  }
+  for (uint32_t b = threadIdx.x + PER * uint32_t(kMpCrown); b < nchunks; b += kMpCrown) {
+    const uint32_t m = later_mask[b];
+    if (m) atomicMax(&lvl_hi, 31 - __builtin_clz(m));
+  }
+  __syncthreads();
+  for (int l = lvl_hi; l >= 0; --l) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+      if ((masks[j] >> l) & 1u) {
+        const uint32_t b = threadIdx.x + uint32_t(j) * uint32_t(kMpCrown);
+        ot_multipole_cell<T, D>(tree, cells[later[b * uint32_t(ML) + uint32_t(l)]].node);
+      }
+    for (uint32_t b = threadIdx.x + PER * uint32_t(kMpCrown); b < nchunks; b += kMpCrown)
+      if ((later_mask[b] >> l) & 1u) ot_multipole_cell<T, D>(tree, cells[later[b * uint32_t(ML) + uint32_t(l)]].node);
+    __threadfence_block();
+    __syncthreads();  // (waits for the stores: the next level reads them back)
   }
 }
 
@@ -1507,7 +2152,8 @@ __global__ __launch_bounds__(64) void ot_force_isa_f32_kernel(const ot_node<floa
 struct nbody_octree {
   int dtype = 0, dim = 0, device = 0;  // device: nbody_octree_create_on's (nbody_octree_create: the current one); every call runs there
   int walk = 0;                        // nbody_octree_set_walk: 0 auto, 1 compiler-scheduled kernel, 2 the visit round as ISA
-  int build = 0;                       // nbody_octree_set_build: 0 / 1 = one launch per level, 2 = all levels in one launch (grid barrier)
+  int build = 0;                       // nbody_octree_set_build: 0 auto (= 3), 1 one launch per level, 2 all levels in one launch
+                                       // (grid barrier), 3 one pass over the sorted keys (ot_build_lcp_kernel)
   int depth_hint = 64;                 // levels launched one by one (the rest share one launch); from the last nbody_octree_info
   int ncu = 0;                         // compute units of the device (the all-level kernels launch at most one block per CU)
   uint32_t step_budget = 0;            // nbody_octree_set_step_budget: visit rounds a body may make; 0 = the node pool size
@@ -1522,7 +2168,14 @@ struct nbody_octree {
   void* groups     = nullptr;  // ot_group<T,D>[max_cells]: sibling group g = nodes 1 + g * 2^D ...
   size_t group_bytes = 0;
   nbody::ot_cell* cells = nullptr;
-  uint32_t* lvl_count = nullptr;  // [MAXL + 2] then flags[1]
+  nbody::ot_cell* tops  = nullptr;  // one-pass build: the cells at the key depth, for ot_build_deep_kernel
+  int8_t* lcp           = nullptr;  // one-pass build: l_i for positions 0 ... n
+  uint32_t* plocal      = nullptr;  //   block-local exclusive prefix of the cells starting at each position
+  uint32_t* bsum        = nullptr;  //   per-block sums -> bases
+  uint32_t* bhist       = nullptr;  //   per-block cells per level
+  uint32_t* later       = nullptr;  //   ranks left to ot_multipole_crown_kernel: slot (chunk, level)
+  uint32_t* later_mask  = nullptr;  //   per chunk: the levels whose slot is in use
+  uint32_t* lvl_count = nullptr;  // [MAXL + 2] level counts and deep groups, flags, two barrier counters, deep-list cursor, crown count
   uint32_t* counters = nullptr;
   int sorted_buf   = 0;
   bool counters_on = false, have_bounds = false, inserted = false, have_tree = false;
@@ -1564,6 +2217,27 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   if (int r = radix_sort_pairs(t->keys, t->idx, n, D == 3 ? 63 : 64, t->hist, st, &fin)) return r;
   t->sorted_buf = fin;
   uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
+  if (t->build == 0 || t->build == 3) {  // one pass over the sorted keys: 4 launches whatever the depth
+    const uint32_t nblk = n / kLcpB + 1;  // positions 0 ... n
+    hipLaunchKernelGGL((ot_lcp_kernel<D>), dim3(nblk), dim3(kLcpB), 0, st, t->keys[fin], n, t->lcp, t->plocal, t->bsum, t->bhist);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL((ot_lcp_finish_kernel<T, D>), dim3(1), dim3(1024), 0, st, n, nblk, t->bsum, t->bhist,
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->lvl_count);
+    NB_HIP(hipGetLastError());
+    {
+      const ot_lcp_args<T, D> args{t->keys[fin], t->idx[fin], n, t->lcp, t->plocal, t->bsum, static_cast<const T*>(s->m),
+                                   static_cast<const T*>(s->x), tree, t->cells, t->tops, t->lvl_count, flags, t->capacity, t->max_cells};
+      const uint32_t position_blocks = uint32_t((uint64_t(n) * NCH + kLcpBuildB - 1) / kLcpBuildB);
+      const uint32_t top_blocks      = (kTopCells<D> * NCH + kLcpBuildB - 1) / kLcpBuildB;
+      hipLaunchKernelGGL((ot_build_lcp_kernel<T, D>), dim3(position_blocks + top_blocks), dim3(kLcpBuildB), 0, st, args, position_blocks);
+      NB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
+                       static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), tree, t->cells,
+                       t->tops, t->lvl_count, flags, t->capacity);
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
   hipLaunchKernelGGL((ot_build_init_kernel<T, D>), dim3(1), dim3(64), 0, st, n, static_cast<const T*>(s->m),
                      static_cast<const T*>(s->x), tree, t->cells, t->lvl_count);
   NB_HIP(hipGetLastError());
@@ -1595,7 +2269,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   // cells still holding >= 2 bodies at the key depth (none in a typical step: the kernel then returns at once)
   hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
                      static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), tree, t->cells,
-                     t->lvl_count, flags, t->capacity);
+                     static_cast<const ot_cell*>(nullptr), t->lvl_count, flags, t->capacity);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -1604,6 +2278,23 @@ template <typename T, int D>
 static int ot_tree_run(nbody_octree* t, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
   const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
+  if ((t->build == 0 || t->build == 3) && (t->max_cells + kMpChunk - 1) / kMpChunk > uint32_t(kMpCrown)) {
+    for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
+      hipLaunchKernelGGL((ot_multipole_ranks_level_kernel<T, D>), dim3((t->max_cells + kOB - 1) / kOB), dim3(kOB), 0, st, l, tree,
+                         t->cells, t->lvl_count, t->capacity, t->max_cells);
+      NB_HIP(hipGetLastError());
+    }
+    return NBODY_OK;
+  }
+  if (t->build == 0 || t->build == 3) {  // rank chunks, then the cells that span chunk boundaries
+    hipLaunchKernelGGL((ot_multipole_chunks_kernel<T, D>), dim3((t->max_cells + kMpChunk - 1) / kMpChunk), dim3(kMpChunk), 0, st, tree,
+                       t->cells, t->lvl_count, t->later, t->later_mask, t->capacity, t->max_cells);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL((ot_multipole_crown_kernel<T, D>), dim3(1), dim3(kMpCrown), 0, st, tree, t->cells, t->lvl_count, t->later,
+                       t->later_mask, t->max_cells);
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
   const int own = t->build == 2 ? 0 : (t->depth_hint < kMaxLevels<D> ? t->depth_hint : kMaxLevels<D>);
   if (own < kMaxLevels<D>) {  // the levels below `own`, deepest first, in one launch (see ot_insert_run)
     uint32_t grid = (t->n / 2 + 1 + kOB - 1) / kOB;
@@ -1696,9 +2387,11 @@ extern "C" int nbody_octree_set_walk(nbody_octree* t, int mode) {
 
 extern "C" int nbody_octree_set_build(nbody_octree* t, int mode) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
-  NB_ARG(mode >= 0 && mode <= 2, "build form must be 0 (auto), 1 (one launch per level) or 2 (all levels in one launch), got %d", mode);
+  NB_ARG(mode >= 0 && mode <= 4,
+         "build form must be 0 (auto), 1 (one launch per level), 2 (all levels in one launch), 3 (one pass over the sorted keys) or 4 "
+         "(one launch per level the last tree used, one for the rest), got %d", mode);
   t->build = mode;
-  if (mode == 1) t->depth_hint = 64;  // every level its own launch, whatever earlier trees looked like
+  if (mode != 4) t->depth_hint = 64;  // 1: every level its own launch, whatever earlier trees looked like
   return NBODY_OK;
 }
 
@@ -1754,9 +2447,19 @@ extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, ui
                                       : (dim == 3 ? sizeof(ot_group<double, 3>) : sizeof(ot_group<double, 2>));
   NB_ALLOC(t->groups, t->group_bytes * size_t(t->max_cells));
   NB_ALLOC(t->cells, sizeof(ot_cell) * size_t(t->max_cells));
-  NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 5));  // level counts, deep groups, flags, two grid-barrier counters
+  NB_ALLOC(t->lvl_count, sizeof(uint32_t) * size_t(maxl + 8));  // level counts, deep groups, flags, two grid-barrier counters, ...
+  {
+    const size_t nblk = size_t(n) / kLcpB + 1;
+    NB_ALLOC(t->tops, sizeof(ot_cell) * (size_t(n) / 2 + 2));
+    NB_ALLOC(t->lcp, size_t(n) + 2);
+    NB_ALLOC(t->plocal, sizeof(uint32_t) * (size_t(n) + 1));
+    NB_ALLOC(t->bsum, sizeof(uint32_t) * nblk);
+    NB_ALLOC(t->bhist, sizeof(uint32_t) * nblk * size_t(maxl + 1));
+    NB_ALLOC(t->later, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2) * size_t(maxl));
+    NB_ALLOC(t->later_mask, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2));
+  }
 #undef NB_ALLOC
-  if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 5)); e != hipSuccess) return fail(e, "hipMemset");
+  if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 8)); e != hipSuccess) return fail(e, "hipMemset");
   {
     hipDeviceProp_t prop;
     if (hipError_t e = hipGetDeviceProperties(&prop, device); e != hipSuccess) return fail(e, "hipGetDeviceProperties");
@@ -1779,6 +2482,13 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
   (void)hipFree(t->rootrec);
   (void)hipFree(t->groups);
   (void)hipFree(t->cells);
+  (void)hipFree(t->tops);
+  (void)hipFree(t->lcp);
+  (void)hipFree(t->plocal);
+  (void)hipFree(t->bsum);
+  (void)hipFree(t->bhist);
+  (void)hipFree(t->later);
+  (void)hipFree(t->later_mask);
   (void)hipFree(t->lvl_count);
   (void)hipFree(t->counters);
   delete t;
@@ -1896,7 +2606,7 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
   int deepest = -1;
   for (int l = 0; l < maxl; ++l)
     if (lv[l] != 0) deepest = l;
-  t->depth_hint = deepest + 3 < maxl ? deepest + 3 : maxl;  // the levels the next builds launch one by one: what this tree used + 2
+  if (t->build == 4) t->depth_hint = deepest + 3 < maxl ? deepest + 3 : maxl;  // the levels the next builds launch one by one
   uint64_t cells = 0;
   for (int l = 0; l <= maxl + 1; ++l) cells += lv[l];  // breadth-first levels, then the groups of the deep build
   if (tree_size) *tree_size = uint32_t(1 + cells * (1u << t->dim));  // next_free_child_group (src/octree.h:152)

@@ -505,19 +505,23 @@ def test_octree_walk_stack_full_and_step_budget_exits(nb, oracle, form):
 
 @pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2), (0, 2)])
 def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
-    """Three ways to launch the breadth-first build and the multipole pass: one launch per level (1); auto (0): one launch per
-    level the previous tree used (+ 2) and ONE launch that walks all deeper levels behind a grid barrier — the second build of
-    each case below runs with the depth the first one reported; every level behind the grid barrier (2).  Same tree size, same
-    root monopole, same per-body counters and accelerations, bit for bit — also with cells below the key depth, with a 60-level
-    chain of nested cells (the deeper levels are NOT empty for a hint taken from a shallow tree), and for two bodies."""
-    cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2)]
+    """The ways to build the tree from the sorted keys: breadth-first with one launch per level (1), with one launch per level the
+    previous tree used (+ 2) and ONE launch that walks all deeper levels behind a grid barrier (4 — the second build of each
+    case below runs with the depth the first one reported), with every level behind the grid barrier (2); and in one pass from
+    the common key prefixes of neighbouring bodies (3 = auto, 0), which numbers the sibling groups in pre-order instead of
+    breadth-first.  Same tree size, same root monopole, same per-body counters and accelerations, bit for bit — also with cells
+    below the key depth, with a 60-level chain of nested cells (the deeper levels are NOT empty for a hint taken from a shallow
+    tree; in the one-pass build one position starts 20 cells), for two and three bodies, and for sizes around the 1024-position
+    blocks of the prefix sum."""
+    cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2), ("uniform", 3), ("uniform", 1023), ("uniform", 1024),
+             ("uniform", 1025), ("galaxy", 2049)]
     if dim == 3:
         cases.append(("plummer", 5000))
     for wl, n in cases:
         res = []
-        for form in (2, 1, 0):
+        for form in (2, 1, 4, 3, 0):
             hs = nb.build_model(dtype, dim, wl, n)
-            if wl == "uniform":  # pairs far below the key resolution and an escaper that inflates the root cube
+            if wl == "uniform" and n > 1000:  # pairs far below the key resolution and an escaper that inflates the root cube
                 hs.x[1] = hs.x[0] + (1e-9 if dtype == 1 else 1e-6)
                 hs.x[5] = 4e3
             dev = nb.DeviceSystem.from_host(hs)
@@ -534,8 +538,8 @@ def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
             assert np.array_equal(res[0][2], r[2]) and np.array_equal(res[0][3], r[3]), (wl, n)
     if dtype == 1 and dim == 3:
         outs = []
-        for form in (2, 1, 0):
-            # auto: the hint comes from a shallow tree first (a galaxy of as many bodies), then the chain is built with it
+        for form in (2, 1, 4, 3, 0):
+            # 4: the hint comes from a shallow tree first (a galaxy of as many bodies), then the chain is built with it
             shallow = nb.build_model(1, 3, "galaxy", _deep_chain(nb, 60).n)
             dev = nb.DeviceSystem.from_host(shallow)
             dev.octree.set_build(form)

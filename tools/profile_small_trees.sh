@@ -1,9 +1,19 @@
+# rocprofv3 kernel statistics of the CLI's recorded step loop at the reference's benchmark-matrix size and at 10^6 bodies
+# (octree: the default one-pass build; bvh), summarised per step into gpurun_out/<tag>/small_trees_kernel_stats.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r03
+O=$R/gpurun_out/${1:-r03}
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_oct1e5 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 100000 -s 210 --precision double --algorithm octree --workload galaxy --csv-total > $O/trace_oct1e5.txt 2>&1
-f=$(find $O/trace_oct1e5 -name "*kernel_stats.csv" | head -1); cp $f $O/oct1e5_kernel_stats.csv
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bvh1e5 -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n 100000 -s 210 --precision double --algorithm bvh --workload galaxy --csv-total > $O/trace_bvh1e5.txt 2>&1
-f=$(find $O/trace_bvh1e5 -name "*kernel_stats.csv" | head -1); cp $f $O/bvh1e5_kernel_stats.csv
-cat $O/trace_oct1e5.txt $O/trace_bvh1e5.txt | tail -4
+S=210
+: > $O/small_trees_kernel_stats.txt
+for cfg in "octree 100000 double" "octree 100000 float" "bvh 100000 double" "octree 1000000 double"; do
+  set -- $cfg
+  tag=$1_$2_$3
+  rm -rf $O/trace_$tag
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$tag -- $R/stdpar-nbody_amd/bin/nbody_hip_d3 -n $2 -s $S --precision $3 --algorithm $1 --workload galaxy --csv-total > $O/trace_$tag.txt 2>&1 || exit 1
+  f=$(find $O/trace_$tag -name "*kernel_stats.csv" | head -1)
+  cp $f $O/${tag}_kernel_stats.csv
+  python3 $R/tools/summarize_kernel_stats.py $f $S "$tag" >> $O/small_trees_kernel_stats.txt
+  rm -rf $O/trace_$tag
+done
+cat $O/small_trees_kernel_stats.txt

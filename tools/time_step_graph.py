@@ -1,5 +1,5 @@
 """Diagnostic: ms per whole step of the tree algorithms when the step is recorded once and replayed (what the CLI's default and
---csv-total modes do), galaxy, theta 0.5 — the octree with its levels as one launch each against all levels in one launch.
+--csv-total modes do), galaxy, theta 0.5 — the octree with every build form (nbody_octree_set_build).
     python tools/time_step_graph.py [float]"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
@@ -27,10 +27,10 @@ def per_step(dev, step, steps=200):
 
 for n in (10000, 100000, 1000000):
     row = []
-    for form in (1, 0, 2):
+    for form in (1, 4, 2, 3):
         dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
         dev.octree.set_build(form)
-        dev.octree_force(0.5); dev.octree.info(dev.stream)   # auto: the tree's depth is known from here on
+        dev.octree_force(0.5); dev.octree.info(dev.stream)   # build 4: the tree's depth is known from here on
         row.append("octree build=%d %.3f" % (form, per_step(dev, lambda: (dev.octree_force(0.5), dev.accelerate_step()), 200 if n < 1000000 else 50)))
         dev.octree.info(dev.stream)
         dev.close()

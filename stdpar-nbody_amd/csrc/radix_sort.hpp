@@ -150,6 +150,10 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
 // hist needs 256 * (nblk + 1) u32, nblk = radix_sort_blocks(n).  Sorts by key bits [0, key_bits): the pairs start in
 // (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.
 inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
+// Tried and not kept (round 3): taking the NEXT pass's histogram inside the scatter — it knows the block every key lands in —
+// with one global atomicAdd per key into three rotating histogram buffers (7 launches fewer per sort).  Bit-exact, but the
+// octree step at N = 10^5 went from 0.445 to 0.525 ms: 10^5 device-scope atomics per pass cost more than the 4.8 us launch
+// they replace, and (block, next digit) pairs of one block's keys are nearly all distinct, so LDS cannot pre-aggregate them.
 // Measured (profiles/r03/small_trees_kernel_stats.txt): at 49 blocks (N = 10^5) the fused scatter takes 13.2 us against 8 + 5 for
 // scatter + scan — nothing gained; at 5 blocks (N = 10^4) the octree step goes from 0.324 to 0.278 ms.
 constexpr uint32_t kSortFusedBlocks = 16;  // up to 32 768 keys: every block scans the 256 x nblk histogram itself

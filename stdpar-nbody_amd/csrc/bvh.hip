@@ -66,6 +66,19 @@ struct nbody_bvh {
 
 namespace nbody {
 
+// ... and back in ONE launch (five hipMemcpyAsync were five dependent launches, 5 us each, per step)
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void ungather_kernel(const T* __restrict__ tmp, uint32_t n, T* __restrict__ m, T* __restrict__ x,
+                                                      T* __restrict__ v, T* __restrict__ a, T* __restrict__ ao) {
+  const uint64_t e = uint64_t(blockIdx.x) * kB + threadIdx.x, nd = uint64_t(n) * D;
+  if (e >= nd) return;
+  x[e]  = tmp[e];
+  v[e]  = tmp[nd + e];
+  a[e]  = tmp[nd * 2 + e];
+  ao[e] = tmp[nd * 3 + e];
+  if (e < n) m[e] = tmp[nd * 4 + e];
+}
+
 // ------------------------------------------------------------------------------------------------
 // K4 bounding box  (src/bvh.h:17-22, src/vec.h:382-405)
 // min over i of fl(p_i - tol) == fl(min_i p_i - tol) (rounding is monotone), so the raw coordinates
@@ -222,7 +235,7 @@ __device__ __forceinline__ uint64_t hilbert_key(uint32_t (&xx)[D]) {
 
 template <typename T, int D>
 __global__ __launch_bounds__(kB) void hilbert_keys_kernel(const T* __restrict__ x, uint32_t n, const T* __restrict__ bbox,
-                                                          uint64_t* __restrict__ keys) {
+                                                          uint64_t* __restrict__ keys, uint64_t* __restrict__ sort_copy) {
 #pragma clang fp contract(off)
   uint64_t i = uint64_t(blockIdx.x) * kB + threadIdx.x;
   if (i >= n) return;
@@ -233,7 +246,9 @@ __global__ __launch_bounds__(kB) void hilbert_keys_kernel(const T* __restrict__ 
     // cast<uint32_t> of an out-of-range value: x86-64 converts through 64 bits and keeps the low half
     cell[k] = uint32_t(static_cast<long long>(q));
   }
-  keys[i] = hilbert_key<D>(cell);
+  const uint64_t key = hilbert_key<D>(cell);
+  keys[i]      = key;  // kept for nbody_bvh_read(what = 0)
+  sort_copy[i] = key;  // the buffer the sort starts from (a separate copy was one more dependent launch per step)
 }
 
 // gather all five state arrays through the permutation into tmp (then copied back)
@@ -1307,10 +1322,8 @@ template <typename T, int D>
 static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   const uint32_t n = s->sz;
   hipLaunchKernelGGL((hilbert_keys_kernel<T, D>), dim3((n + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->x), n,
-                     static_cast<const T*>(t->bbox), t->keys[0]);
+                     static_cast<const T*>(t->bbox), t->keys[0], t->keys[1]);
   NB_HIP(hipGetLastError());
-  // keys[0] must survive for nbody_bvh_read(what=0): sort from a copy
-  NB_HIP(hipMemcpyAsync(t->keys[1], t->keys[0], sizeof(uint64_t) * n, hipMemcpyDeviceToDevice, st));
   // the sort ping-pongs between keys[1] and a key buffer carved from tmp (keys[0] is kept for nbody_bvh_read)
   uint64_t* kbuf[2]   = {t->keys[1], reinterpret_cast<uint64_t*>(t->tmp)};
   const int key_bits  = (D == 2) ? 64 : 63;
@@ -1323,12 +1336,19 @@ static int sort_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
                      static_cast<const T*>(s->x), static_cast<const T*>(s->v), static_cast<const T*>(s->a),
                      static_cast<const T*>(s->ao), tmp);
   NB_HIP(hipGetLastError());
-  const size_t vb = sizeof(T) * size_t(n) * D;
-  NB_HIP(hipMemcpyAsync(s->x, tmp, vb, hipMemcpyDeviceToDevice, st));
-  NB_HIP(hipMemcpyAsync(s->v, tmp + size_t(n) * D, vb, hipMemcpyDeviceToDevice, st));
-  NB_HIP(hipMemcpyAsync(s->a, tmp + size_t(n) * D * 2, vb, hipMemcpyDeviceToDevice, st));
-  NB_HIP(hipMemcpyAsync(s->ao, tmp + size_t(n) * D * 3, vb, hipMemcpyDeviceToDevice, st));
-  NB_HIP(hipMemcpyAsync(s->m, tmp + size_t(n) * D * 4, sizeof(T) * size_t(n), hipMemcpyDeviceToDevice, st));
+  if (n <= (1u << 18)) {  // launch-bound sizes: one kernel; beyond, the runtime's copy kernels are the faster way to move 5 arrays
+    hipLaunchKernelGGL((ungather_kernel<T, D>), dim3(uint32_t((uint64_t(n) * D + kB - 1) / kB)), dim3(kB), 0, st, tmp, n,
+                       static_cast<T*>(s->m), static_cast<T*>(s->x), static_cast<T*>(s->v), static_cast<T*>(s->a),
+                       static_cast<T*>(s->ao));
+    NB_HIP(hipGetLastError());
+  } else {
+    const size_t vb = sizeof(T) * size_t(n) * D;
+    NB_HIP(hipMemcpyAsync(s->x, tmp, vb, hipMemcpyDeviceToDevice, st));
+    NB_HIP(hipMemcpyAsync(s->v, tmp + size_t(n) * D, vb, hipMemcpyDeviceToDevice, st));
+    NB_HIP(hipMemcpyAsync(s->a, tmp + size_t(n) * D * 2, vb, hipMemcpyDeviceToDevice, st));
+    NB_HIP(hipMemcpyAsync(s->ao, tmp + size_t(n) * D * 3, vb, hipMemcpyDeviceToDevice, st));
+    NB_HIP(hipMemcpyAsync(s->m, tmp + size_t(n) * D * 4, sizeof(T) * size_t(n), hipMemcpyDeviceToDevice, st));
+  }
   return NBODY_OK;
 }
 

@@ -154,6 +154,9 @@ inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSo
 // with one global atomicAdd per key into three rotating histogram buffers (7 launches fewer per sort).  Bit-exact, but the
 // octree step at N = 10^5 went from 0.445 to 0.525 ms: 10^5 device-scope atomics per pass cost more than the 4.8 us launch
 // they replace, and (block, next digit) pairs of one block's keys are nearly all distinct, so LDS cannot pre-aggregate them.
+// Also tried and not kept: 11-bit digits (6 passes instead of 8; 2048 bins, 40 KB of LDS in the scatter, 11 ballots per strip).
+// Octree step, graph replay, before -> after: N = 10^4 0.214 -> 0.226 ms, 10^5 0.445 -> 0.437, 10^6 2.81 -> 2.92 — the two
+// passes saved are paid back by the wider bins everywhere but at 10^5.
 // Measured (profiles/r03/small_trees_kernel_stats.txt): at 49 blocks (N = 10^5) the fused scatter takes 13.2 us against 8 + 5 for
 // scatter + scan — nothing gained; at 5 blocks (N = 10^4) the octree step goes from 0.324 to 0.278 ms.
 constexpr uint32_t kSortFusedBlocks = 16;  // up to 32 768 keys: every block scans the 256 x nblk histogram itself

@@ -7,8 +7,8 @@ from _experiments import load_package
 nb = load_package()
 sizes = [int(a) for a in sys.argv[1:]] or [65536, 100000, 262144]
 for n in sizes:
-    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "galaxy", n))
-    for count in (n, n // 8):
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, os.environ.get("WL", "galaxy"), n))
+    for count in (n,) if os.environ.get("FULL_ONLY") else (n, n // 8):
         for y in (1, 2, 4, 8, 16, 32, 64):
             for r in (1, 2):
                 os.environ["NBODY_K1_CHUNKS"] = str(y)

@@ -1069,6 +1069,7 @@ __global__ __launch_bounds__(kOB) void ot_multipole_ranks_level_kernel(int level
                                                                        const uint32_t* __restrict__ lvl_count, uint32_t capacity,
                                                                        uint32_t max_cells) {
   constexpr uint32_t NCH = 1u << D;
+  if (lvl_count[level] == 0) return;  // (a level the tree does not reach: the launch is all it costs)
   uint32_t total = ot_lcp_total<T, D>(lvl_count);
   if (total > max_cells) total = max_cells;
   const uint32_t r = blockIdx.x * kOB + threadIdx.x;

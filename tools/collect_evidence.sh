@@ -27,5 +27,7 @@ cd $R; timeout -k 10 120 python3 tools/time_energy.py > $O/energy_times.txt 2>&1
 { timeout -k 10 120 python3 tools/time_octree.py 1000000 double; timeout -k 10 120 python3 tools/time_octree.py 1000000 float; timeout -k 10 60 python3 tools/time_octree.py 100000 float; } > $O/octree_times.txt 2>&1
 timeout -k 10 200 python3 tools/time_step_graph.py > $O/step_graph.txt 2>&1; timeout -k 10 200 python3 tools/time_step_graph.py float >> $O/step_graph.txt 2>&1
 PREC=float TAG=pmc_otf bash tools/pmc_kernel.sh ot_force_isa_f32 octree 1000000 "$C1" "$C2" "FETCH_SIZE" > $O/pmc_octree_walk_f32.txt 2>&1
+(for d in 3 2; do for p in double float; do timeout -k 10 120 python3 tools/time_octree.py 1000000 $p galaxy $d || exit 1; done; done) 2>&1 | grep -v amdgpu > $O/octree_times_walks.txt
+bash tools/profile_small_trees.sh $TAG > /dev/null 2>&1
 cd /tmp
 find $O/trace_k2 $O/trace_k9 $O/trace_energy -name "*kernel_stats.csv" | while read f; do echo $f; head -6 $f; done

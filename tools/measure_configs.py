@@ -6,16 +6,20 @@ from conftest import load_package
 nb = load_package()
 
 
-def timed(dev, fn, reps, warm=1):
-    """ms per call at the clock the box sustains: `warm` > 0 runs fn for 0.2 s first (a process's first case otherwise reads
-    up to 12 % slow), then the best of three windows of `reps` calls."""
-    if warm:
+def timed(dev, fn, reps, warm=1, warm_s=0.0):
+    """ms per call: `warm` calls first, then fn for `warm_s` seconds (up to the clock the box sustains: a process's first case
+    otherwise reads up to 12 % slow), then the best of three windows of `reps` calls when warmed by time, one window otherwise
+    (a tree step integrates the system: hundreds of warm-up steps would time an evolved galaxy, not the initial one)."""
+    for _ in range(warm):
+        fn()
+    dev.sync()
+    if warm_s > 0:
         t0 = time.perf_counter()
-        while time.perf_counter() - t0 < 0.2:
+        while time.perf_counter() - t0 < warm_s:
             fn()
             dev.sync()
     best = 1e9
-    for _ in range(3 if warm else 1):
+    for _ in range(3 if warm_s > 0 else 1):
         dev.sync()
         t0 = time.perf_counter()
         for _ in range(reps):
@@ -35,7 +39,7 @@ def all_pairs(name, dtype, dim, wl, n, reps, collapsed=False, first=0, count=Non
         else:
             dev.all_pairs_force(first, cnt)
         dev.accelerate_step(first, cnt)
-    t = timed(dev, step, reps)
+    t = timed(dev, step, reps, warm_s=0.2)
     flop = 20.0 if dim == 3 else 14.0
     peak = 157.3 if dtype == nb.F32 else 78.6
     tf = flop * cnt * (n - 1) / t / 1e12

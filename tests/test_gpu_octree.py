@@ -325,6 +325,34 @@ def test_octree_errors(nb):
         d2.octree.compute_force(d2.state(), 0.5, d2.stream)
 
 
+@pytest.mark.parametrize("form", [3, 1, 4, 2])
+def test_octree_node_pool_exhausted_above_the_key_depth(nb, oracle, form):
+    """Ten pairs 2^-18 of the root side apart make ten chains of ~17 nested cells: 170 sibling groups against the 125 the
+    reference's pool holds for 20 bodies (System::max_tree_node_size = max(1000, 8 n) nodes, src/system.h:30).  The oracle's
+    insertion overflows; every build form reports it through nbody_octree_info — the one-pass build through the check each cell
+    and its parent make on the cell's rank — leaves the cells it cannot place as empty leaves, and the walk of what was built
+    terminates with finite accelerations inside its buffer."""
+    rng = np.random.default_rng(3)
+    hs = nb.HostSystem(1, 3, 20)
+    hs.m[:] = 1.0
+    base = rng.uniform(-1, 1, (10, 3))
+    hs.x[0::2] = base
+    hs.x[1::2] = base + 4.0 / (1 << 18)
+    hs.c, hs.dt = 1.0, 1e-3
+    ref = oracle.State(1, 3, 20)
+    ref.m[:], ref.x[:], ref.c = hs.m, hs.x, 1.0
+    with pytest.raises(RuntimeError):
+        oracle.octree_step_force(ref, 0.5)
+    dev = nb.DeviceSystem.from_host(hs)
+    dev.octree.set_build(form)
+    dev.octree_force(0.5)
+    dev.sync()
+    with pytest.raises(nb.NbodyError, match="node pool exhausted"):
+        dev.octree.info(dev.stream)
+    assert np.all(np.isfinite(dev.download().a))
+    dev.close()
+
+
 def test_octree_run_paths_raise_on_device_flags(nb):
     """A flagged build drops mass (cells still holding >= 2 bodies stay empty leaves): the step loops must not integrate on.
     nb.run() reads the sticky device-side flag every OCTREE_CHECK_EVERY steps and after the last step; ShardedOctree does

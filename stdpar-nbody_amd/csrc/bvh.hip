@@ -350,8 +350,10 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
                                                                 T* __restrict__ box) {
 #pragma clang fp contract(off)
   for (int l = l_hi; l >= l_lo; --l) {
-    const uint32_t first = (1u << l) - 1u, count = 1u << l;
-    for (uint32_t li = blockIdx.x * kB + threadIdx.x; li < count; li += gridDim.x * kB) {
+    // block b owns nodes [b, b + 1) * count / blocks of every level it walks: the subtree chunk under its nodes of level l_lo
+    const uint32_t first = (1u << l) - 1u, count = 1u << l, share = count / gridDim.x;
+    for (uint32_t q = threadIdx.x; q < share; q += kB) {
+      const uint32_t li = blockIdx.x * share + q;
       const uint32_t i  = first + li;
       const uint32_t bl = li * 2 + first + count, br = bl + 1;
       const tree_rec<T> ml = node[bl];
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
     }
     if (l > l_lo) {
       __threadfence_block();
-      __syncthreads();  // single-block multi-level mode only
+      __syncthreads();  // the next level up reads what this block wrote (nothing of any other block's)
     }
   }
 }
@@ -1361,14 +1363,20 @@ static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   hipLaunchKernelGGL((build_leaf_level_kernel<T, D>), dim3((cnt + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->m),
                      static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, t->nnodes, node, box);
   NB_HIP(hipGetLastError());
-  int l = last - 1;
-  for (; l >= 0 && (1u << l) > uint32_t(kB); --l) {
-    hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3((1u << l) / kB), dim3(kB), 0, st, l, l, node, box);
-    NB_HIP(hipGetLastError());
-  }
-  if (l >= 0) {
-    hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3(1), dim3(kB), 0, st, l, 0, node, box);
-    NB_HIP(hipGetLastError());
+  // Nine levels per launch: a block takes 256 nodes of the deepest one and follows their subtree chunk up to its single node nine
+  // levels higher, with block barriers between the levels (one launch per level was 8 dependent launches at N = 10^5, 11 at 10^6);
+  // the top levels, from 256 nodes on, are one block's.
+  for (int l = last - 1; l >= 0;) {
+    if ((1u << l) > uint32_t(kB)) {
+      const int lo = l - 8 > 0 ? l - 8 : 0;
+      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3((1u << l) / kB), dim3(kB), 0, st, l, lo, node, box);
+      NB_HIP(hipGetLastError());
+      l = lo - 1;
+    } else {
+      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3(1), dim3(kB), 0, st, l, 0, node, box);
+      NB_HIP(hipGetLastError());
+      l = -1;
+    }
   }
   return NBODY_OK;
 }

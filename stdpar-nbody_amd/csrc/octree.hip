@@ -515,6 +515,7 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
   };
   frame stack[kOtDeepFrames];
   for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+    if (tops == cells + base && base + k >= capacity / NCH + 1u) break;  // the per-level list ran out of room (flagged when it did)
     const ot_cell top = tops[k];
     int sp            = 0;
     stack[sp++]       = frame{top.node, top.start, top.end, uint32_t(ML)};
@@ -646,12 +647,13 @@ __device__ __forceinline__ void ot_multipole_cell(ot_tree<T, D> tree, uint32_t n
 template <typename T, int D>
 __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_tree<T, D> tree,
                                                                  const ot_cell* __restrict__ cells,
-                                                                 const uint32_t* __restrict__ lvl_count) {
+                                                                 const uint32_t* __restrict__ lvl_count, uint32_t max_cells) {
   const uint32_t count = lvl_count[level];
   const uint32_t k     = blockIdx.x * kOB + threadIdx.x;
   if (k >= count) return;
   uint32_t base = 0;
   for (int j = 0; j < level; ++j) base += lvl_count[j];
+  if (base + k >= max_cells) return;  // cells the list had no room for (the build raised kFlagCapacity): counted, never stored
   ot_multipole_cell<T, D>(tree, cells[base + k].node);
 }
 
@@ -660,7 +662,7 @@ __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_t
 template <typename T, int D>
 __global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
                                                                       const uint32_t* __restrict__ lvl_count, uint32_t* counter,
-                                                                      uint32_t* flags, int lowest_level) {
+                                                                      uint32_t* flags, int lowest_level, uint32_t max_cells) {
   uint32_t cnt[kMaxLevels<D>], total = 0;
 #pragma unroll
   for (int l = 0; l < kMaxLevels<D>; ++l) {
@@ -672,7 +674,8 @@ __global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T,
     const uint32_t count = cnt[l];
     if (count == 0) continue;
     base -= count;
-    for (uint32_t k = blockIdx.x * kOB + threadIdx.x; k < count; k += gridDim.x * kOB) ot_multipole_cell<T, D>(tree, cells[base + k].node);
+    for (uint32_t k = blockIdx.x * kOB + threadIdx.x; k < count && base + k < max_cells; k += gridDim.x * kOB)
+      ot_multipole_cell<T, D>(tree, cells[base + k].node);
     if (l > lowest_level && !ot_grid_barrier(counter, epoch, flags)) break;
   }
 }
@@ -2301,7 +2304,7 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
     uint32_t grid = (t->n / 2 + 1 + kOB - 1) / kOB;
     if (grid > uint32_t(t->ncu)) grid = uint32_t(t->ncu);
     hipLaunchKernelGGL((ot_multipole_all_levels_kernel<T, D>), dim3(grid), dim3(kOB), 0, st, tree, t->cells, t->lvl_count,
-                       t->lvl_count + (kMaxLevels<D> + 4), t->lvl_count + (kMaxLevels<D> + 2), own);
+                       t->lvl_count + (kMaxLevels<D> + 4), t->lvl_count + (kMaxLevels<D> + 2), own, t->max_cells);
     NB_HIP(hipGetLastError());
   }
   for (int l = own - 1; l >= 0; --l) {
@@ -2309,7 +2312,7 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
     for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
     const uint64_t cap_l = width < uint64_t(t->n / 2 + 1) ? width : uint64_t(t->n / 2 + 1);
     hipLaunchKernelGGL((ot_multipole_level_kernel<T, D>), dim3(uint32_t((cap_l + kOB - 1) / kOB)), dim3(kOB), 0, st, l,
-                       tree, t->cells, t->lvl_count);
+                       tree, t->cells, t->lvl_count, t->max_cells);
     NB_HIP(hipGetLastError());
   }
   return NBODY_OK;

@@ -325,6 +325,63 @@ def test_octree_errors(nb):
         d2.octree.compute_force(d2.state(), 0.5, d2.stream)
 
 
+@pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2)])
+def test_octree_build_forms_fuzz(nb, dtype, dim):
+    """The one-pass build against the breadth-first one on geometry that random clouds do not produce: bodies exactly on cell
+    boundaries (grid-aligned coordinates: `pos > divide` is false on the boundary), on a line, on a plane, in tight clusters with
+    a far escaper, with many equal coordinates, in sizes around the kernels' block sizes.  Tree size, root monopole, counters and
+    accelerations bit for bit; a case one form refuses (node pool / depth) must be refused by the others.  (Round 3: the first run
+    of this test crashed the BREADTH-FIRST forms — when a level's cell list ran out of room the cells were counted but not stored,
+    and the deep build and the multipole pass read list entries past the allocation.)"""
+    rng = np.random.default_rng(11 + 3 * dtype + dim)
+    t = np.float64 if dtype == 1 else np.float32
+    sizes = [2, 3, 5, 8, 9, 63, 64, 65, 255, 256, 257, 511, 1023, 1024, 1025, 2047, 2048, 3000, 4097]
+    for case in range(40):
+        n = int(sizes[case % len(sizes)])
+        kind = case % 8
+        x = rng.uniform(-1, 1, (n, dim))
+        if kind == 1:    # grid-aligned: multiples of 2^-6, distinct
+            side = int(np.ceil(n ** (1.0 / dim))) + 1
+            idx = rng.permutation(side ** dim)[:n]
+            x = np.stack([(idx // side ** k) % side for k in range(dim)], axis=1) / 64.0
+        elif kind == 2:  # a line
+            x = np.outer(np.sort(rng.uniform(-1, 1, n)), np.ones(dim))
+            x += np.arange(n)[:, None] * 1e-9
+        elif kind == 3:  # a plane / an axis-aligned segment in 2D
+            x[:, 0] = 0.25
+        elif kind == 4:  # tight clusters and an escaper
+            centres = rng.uniform(-1, 1, (max(1, n // 16), dim))
+            x = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 1e-4, (n, dim))
+            x[0] = 50.0
+        elif kind == 5:  # many equal coordinates
+            x = np.round(x * 4) / 4 + rng.uniform(0, 1e-3, (n, dim)) * (rng.uniform(0, 1, (n, dim)) < 0.3)
+            x += np.arange(n)[:, None] * 1e-7
+        elif kind == 6:  # powers of two and their negatives
+            x = np.ldexp(1.0, rng.integers(-20, 2, (n, dim))) * rng.choice([-1.0, 1.0], (n, dim))
+            x += np.arange(n)[:, None] * 1e-6
+        hs = nb.HostSystem(dtype, dim, n)
+        hs.m[:] = rng.uniform(0.5, 1.5, n).astype(t)
+        hs.x[:] = x.astype(t)
+        hs.c, hs.dt = 1.0, 1e-3
+        res = []
+        for form in (1, 3, 4, 2):
+            dev = nb.DeviceSystem.from_host(hs)
+            dev.octree.set_build(form)
+            dev.octree.enable_counters(True)
+            dev.octree_force(0.4)
+            dev.sync()
+            try:
+                info = dev.octree.info(dev.stream)
+            except nb.NbodyError as e:
+                info = ("refused", "node pool" in str(e) or "depth limit" in str(e))
+            res.append((info, dev.octree.read_counters(dev.stream).copy(), dev.download().a.copy()))
+            dev.close()
+        for r in res[1:]:
+            assert res[0][0] == r[0], (case, n, kind, res[0][0], r[0])
+            if res[0][0][0] != "refused":
+                assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]), (case, n, kind)
+
+
 @pytest.mark.parametrize("form", [3, 1, 4, 2])
 def test_octree_node_pool_exhausted_above_the_key_depth(nb, oracle, form):
     """Ten pairs 2^-18 of the root side apart make ten chains of ~17 nested cells: 170 sibling groups against the 125 the

@@ -127,6 +127,62 @@ def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
             assert np.array_equal(res[0][0], r[0]) and np.array_equal(res[0][1], r[1]), (dim, wl, n, theta)
 
 
+@pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2)])
+def test_traversal_forms_fuzz(nb, oracle, dtype, dim):
+    """Every K9 form on geometry random clouds do not produce — bodies on a grid (equal Hilbert cells are excluded: ties are
+    their own test), on a line, on a plane, tight clusters with an escaper, coordinates that are powers of two — at sizes around
+    the 64-body groups and the tree's powers of two: counters equal the oracle's bit for bit, accelerations equal each other bit
+    for bit and the oracle's within tolerance."""
+    rng = np.random.default_rng(5 + 3 * dtype + dim)
+    t = np.float64 if dtype == 1 else np.float32
+    sizes = [2, 3, 5, 63, 64, 65, 127, 128, 129, 255, 257, 1023, 1024, 1025, 2047, 2049, 4097]
+    for case in range(18):
+        n = int(sizes[case % len(sizes)])
+        kind = case % 6
+        x = rng.uniform(-1, 1, (n, dim))
+        if kind == 1:
+            side = int(np.ceil(n ** (1.0 / dim))) + 1
+            idx = rng.permutation(side ** dim)[:n]
+            x = np.stack([(idx // side ** k) % side for k in range(dim)], axis=1) / 8.0
+        elif kind == 2:
+            x = np.outer(np.sort(rng.uniform(-1, 1, n)), np.ones(dim))
+        elif kind == 3:
+            x[:, 0] = 0.25
+        elif kind == 4:
+            centres = rng.uniform(-1, 1, (max(1, n // 16), dim))
+            x = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 1e-3, (n, dim))
+            x[0] = 50.0
+        elif kind == 5:
+            x = np.ldexp(1.0, rng.integers(-6, 3, (n, dim))) * rng.choice([-1.0, 1.0], (n, dim)) + rng.uniform(0, 1e-2, (n, dim))
+        hs = nb.HostSystem(dtype, dim, n)
+        hs.m[:] = rng.uniform(0.5, 1.5, n).astype(t)
+        hs.x[:] = x.astype(t)
+        hs.c, hs.dt = 1.0, 1e-3
+        ref = oracle.State(dtype, dim, n)
+        ref.m[:], ref.x[:], ref.c = hs.m, hs.x, 1.0
+        lo, hi = oracle.bounding_box(ref)
+        keys = oracle.hilbert_keys(ref, lo, hi)
+        if len(np.unique(keys)) != n:
+            continue   # equal keys: the reference's order is unspecified there (test_key_ties_match_the_reference_as_multisets)
+        oracle.apply_perm(ref, oracle.sort_keys(keys))
+        tr = oracle.bvh_build(ref)
+        theta = float(rng.choice([0.0, 0.3, 0.7, 1.5]))
+        ocnt = oracle.bvh_force(ref, tr, theta, want_counts=True)
+        res = []
+        for mode in (1, 3, 5, 0, 6):
+            dev = nb.DeviceSystem.from_host(hs)
+            dev.bvh.set_traversal(mode)
+            dev.bvh.enable_counters(mode != 6)   # (the row sweep has no counters)
+            dev.bvh_force(theta)
+            dev.sync()
+            res.append((dev.download().a.copy(), dev.bvh.read(5, dev.stream) if mode != 6 else None))
+            dev.close()
+        assert np.array_equal(res[0][1], ocnt), (case, n, kind, theta)
+        assert maxrel(res[0][0], ref.a) <= FORCE_TOL[dtype], (case, n, kind, theta)
+        for r in res[1:]:
+            assert np.array_equal(res[0][0], r[0]) and (r[1] is None or np.array_equal(res[0][1], r[1])), (case, n, kind, theta)
+
+
 def test_bvh_theta0_equals_all_pairs(nb):
     """README.md:122-129: theta=0 never approximates => exact all-pairs, in Hilbert order."""
     n = 3000

@@ -325,6 +325,22 @@ def test_octree_errors(nb):
         d2.octree.compute_force(d2.state(), 0.5, d2.stream)
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_octree_build_forms_over_many_steps(nb, dtype):
+    """Sixty recorded-and-replayed steps of an evolving galaxy: the one-pass build reuses its lists, marks and masks from step to
+    step (nothing is cleared in between), so the trajectory must stay bit-identical to the breadth-first build's."""
+    outs = []
+    for form in (1, 3):
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", 30000))
+        dev.octree.set_build(form)
+        nb.run(dev, "octree", 60, 0.5)
+        dev.sync()
+        out = dev.download()
+        outs.append((out.x.copy(), out.v.copy(), dev.octree.info(dev.stream)))
+        dev.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
 @pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2)])
 def test_octree_build_forms_fuzz(nb, dtype, dim):
     """The one-pass build against the breadth-first one on geometry that random clouds do not produce: bodies exactly on cell

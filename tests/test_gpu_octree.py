@@ -614,7 +614,7 @@ def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
     below the key depth, with a 60-level chain of nested cells (the deeper levels are NOT empty for a hint taken from a shallow
     tree; in the one-pass build one position starts 20 cells), for two and three bodies, and for sizes around the 1024-position
     blocks of the prefix sum."""
-    cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2), ("uniform", 3), ("uniform", 1023), ("uniform", 1024),
+    cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2), ("uniform", 1), ("uniform", 3), ("uniform", 1023), ("uniform", 1024),
              ("uniform", 1025), ("galaxy", 2049)]
     if dim == 3:
         cases.append(("plummer", 5000))

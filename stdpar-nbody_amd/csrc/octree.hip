@@ -10,11 +10,15 @@
 //             `divide[i] += (2*(pos[i] > divide[i]) - 1) * half_length` chain (src/octree.h:127-138), and records the
 //             hyperant taken at each of MAXL levels: a 63/64-bit path key
 //   sort      stable LSD radix sort of (key, body) — bodies of a cell are then contiguous
-//   build     breadth first, one launch per level: an internal cell [start, end) finds its 2^D child ranges by binary
-//             search on the next key digit; empty / single-body children become leaves, the others are queued for
-//             the next level.  Children are allocated after their parents, as the traversal requires
-//             (src/octree.h:248-249)
-//   multipoles  one launch per level, deepest first (src/octree.h:183-224, without the latch)
+//   build     in ONE pass (default): every cell follows from the key digits neighbouring sorted bodies share, a prefix sum
+//             numbers all cells in pre-order and every cell is built on its own — its end and its 2^D child ranges from the
+//             sorted keys, the group numbers of its child cells from the same prefix sum (see "one-pass build" below).
+//             Also kept, as cross-checks that give the same tree bit for bit (nbody_octree_set_build): breadth first, one
+//             launch per level — an internal cell [start, end) finds its 2^D child ranges by binary search on the next key
+//             digit; empty / single-body children become leaves, the others are queued for the next level.  Either way
+//             children are allocated after their parents, as the traversal requires (src/octree.h:248-249)
+//   multipoles  children before parents (src/octree.h:183-224, without the latch): two launches over rank chunks (one-pass
+//             build, up to 2.6e5 bodies), otherwise one launch per level, deepest first
 //   force     the reference's walk per body (src/octree.h:226-263) with 2^D lanes per body: the children of an opened node
 //             are examined side by side; every opening decision side/(sqrt(d2)+eps) < theta equals the reference's
 //             bit for bit (quick bracketing test, IEEE sqrt and divide only inside the guard band), so the per-body

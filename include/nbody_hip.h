@@ -181,8 +181,8 @@ int  nbody_octree_set_walk(nbody_octree* t, int mode);
 /* How the tree is built from the sorted path keys and how the multipole pass is launched:
  *   0 = auto (3);
  *   3 = one pass: every cell follows from the common key prefixes of neighbouring bodies, so all cells are numbered by one prefix
- *       sum and built at once (4 launches whatever the depth), and the multipoles take two (rank chunks, then the cells that span
- *       chunk boundaries);
+ *       sum and built at once (4 launches whatever the depth), and the multipoles take two or three (rank chunks, then the cells
+ *       that span chunk boundaries, in two rounds above 2.6e5 bodies);
  *   1 = breadth-first, one launch per tree level for the build and one for the multipoles (21 + 21 in 3D);
  *   4 = as 1 for the levels the tree used at the last nbody_octree_info (+ 2), ONE launch behind a grid barrier for the rest;
  *   2 = every level behind the grid barrier (measured slower on MI355X).

@@ -17,8 +17,8 @@
 //             launch per level — an internal cell [start, end) finds its 2^D child ranges by binary search on the next key
 //             digit; empty / single-body children become leaves, the others are queued for the next level.  Either way
 //             children are allocated after their parents, as the traversal requires (src/octree.h:248-249)
-//   multipoles  children before parents (src/octree.h:183-224, without the latch): two launches over rank chunks (one-pass
-//             build, up to 2.6e5 bodies), otherwise one launch per level, deepest first
+//   multipoles  children before parents (src/octree.h:183-224, without the latch): two or three launches over rank chunks
+//             (one-pass build), otherwise one launch per level, deepest first
 //   force     the reference's walk per body (src/octree.h:226-263) with 2^D lanes per body: the children of an opened node
 //             are examined side by side; every opening decision side/(sqrt(d2)+eps) < theta equals the reference's
 //             bit for bit (quick bracketing test, IEEE sqrt and divide only inside the guard band), so the per-body
@@ -700,7 +700,8 @@ __global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T,
 // The multipoles need children before parents.  In rank order every subtree is an interval, so a block that owns a chunk of ranks
 // can finish, level by level with block barriers only, every cell whose subtree ends inside its chunk
 // (ot_multipole_chunks_kernel); the cells it cannot — the <= kMaxLevels ancestors of each chunk boundary — are listed and
-// finished by ONE block afterwards (ot_multipole_crown_kernel).  Same children, same order, same arithmetic as
+// finished by ONE block afterwards (ot_multipole_crown_kernel), for large trees after a second round of blocks over the list
+// (ot_multipole_round_kernel).  Same children, same order, same arithmetic as
 // ot_multipole_cell: the tree is the per-level build's up to the numbering of the sibling groups, and the walk (which pushes
 // children in slot order) produces bit-identical forces and counters (tests/test_gpu_octree.py::test_octree_build_forms).
 constexpr int kLcpB = 1024;   // positions per block of ot_lcp_kernel
@@ -1184,33 +1185,21 @@ __global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T
   }
 }
 
-// One block: the cells whose subtrees span chunk boundaries, deepest level first.  They sit in the slots (chunk, level) that the
-// chunks' masks name.  Up to kMpCrown of them in up to kMpCrown chunks: compacted, one per thread, the same way as above.
-// More: level by level over the chunks, children read from memory.
-template <typename T, int D>
-__global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
-                                                                  const uint32_t* __restrict__ lvl_count,
-                                                                  const uint32_t* __restrict__ later,
-                                                                  const uint32_t* __restrict__ later_mask, uint32_t max_cells) {
-  constexpr uint32_t NCH = 1u << D;
-  constexpr int ML       = kMaxLevels<D>;
-  __shared__ T sm[kMpCrown][4];
-  __shared__ uint32_t base[kMpCrown + 1];  // compact position of a chunk's first waiting cell
-  __shared__ uint32_t maskl[kMpCrown];     // the chunks' masks
-  __shared__ uint32_t wsum[kMpCrown / 64];
-  __shared__ int lvl_hi;
-  uint32_t total = ot_lcp_total<T, D>(lvl_count);
-  if (total > max_cells) total = max_cells;
-  const uint32_t nchunks = (total + kMpChunk - 1) / kMpChunk;
-  if (nchunks <= 1) return;  // (a single chunk leaves nothing)
-  if (threadIdx.x == 0) lvl_hi = -1;
-  bool fast = nchunks <= uint32_t(kMpCrown);
-  uint32_t count = 0, mymask = 0;
-  if (fast) {  // exclusive prefix of the chunks' waiting cells
-    mymask = threadIdx.x < nchunks ? later_mask[threadIdx.x] : 0u;
-    const uint32_t v    = uint32_t(__builtin_popcount(mymask));
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t inc        = v;
+// The waiting cells of a round sit in the slots (block, level) that the blocks' masks name; in (block, level) order they are in
+// RANK order, so the compacted list has the property the ranks have: the waiting cells below a waiting cell are an interval of
+// it.  Exclusive prefix of the masks' bit counts into LDS (base[nblocks] = the number of waiting cells); returns that number.
+constexpr uint32_t kMpMaxBlocks = 8192;  // blocks of the previous round a round can compact (32 KB of LDS): trees of up to 4.2 * 10^6 cells
+constexpr uint32_t kMpLater2    = 0x40000000u;
+
+__device__ __forceinline__ uint32_t ot_compact_masks(const uint32_t* __restrict__ mask, uint32_t nblocks, uint32_t* base,
+                                                      uint32_t* wsum, uint32_t* carry_s) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) *carry_s = 0;
+  ot_lds_barrier();
+  for (uint32_t b0 = 0; b0 < nblocks; b0 += kMpCrown) {
+    const uint32_t b = b0 + threadIdx.x;
+    const uint32_t v = b < nblocks ? uint32_t(__builtin_popcount(mask[b])) : 0u;
+    uint32_t inc     = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = __shfl_up(inc, off, 64);
@@ -1218,38 +1207,189 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T,
     }
     if (lane == 63) wsum[wave] = inc;
     ot_lds_barrier();
-    uint32_t before = 0;
+    uint32_t before = *carry_s, total = 0;
 #pragma unroll
     for (int w = 0; w < kMpCrown / 64; ++w) {
       const uint32_t q = wsum[w];
       if (uint32_t(w) < wave) before += q;
-      count += q;
+      total += q;
     }
-    base[threadIdx.x]  = before + inc - v;
-    maskl[threadIdx.x] = mymask;
-    if (threadIdx.x == 0) base[kMpCrown] = count;
-    fast = count <= uint32_t(kMpCrown);
+    if (b < nblocks) base[b] = before + inc - v;
+    ot_lds_barrier();
+    if (threadIdx.x == 0) *carry_s += total;
+    ot_lds_barrier();
+  }
+  if (threadIdx.x == 0) base[nblocks] = *carry_s;
+  ot_lds_barrier();
+  return base[nblocks];
+}
+
+// the rank in compact position k: the block whose cells include it (last b with base[b] <= k), then the (k - base[b] + 1)-th set
+// bit of that block's mask names the level slot
+template <int ML>
+__device__ __forceinline__ uint32_t ot_compact_item(uint32_t k, const uint32_t* base, uint32_t nblocks,
+                                                     const uint32_t* __restrict__ mask, const uint32_t* __restrict__ later) {
+  uint32_t b = 0, hi_b = nblocks;
+  while (hi_b - b > 1) {
+    const uint32_t mid = b + (hi_b - b) / 2;
+    if (base[mid] <= k) b = mid;
+    else hi_b = mid;
+  }
+  uint32_t m = mask[b];
+  for (uint32_t skip = k - base[b]; skip > 0; --skip) m &= m - 1u;
+  return later[b * uint32_t(ML) + uint32_t(__builtin_ctz(m))];
+}
+__device__ __forceinline__ uint32_t ot_compact_slot(uint32_t slot, int ML, const uint32_t* base, const uint32_t* __restrict__ mask) {
+  const uint32_t b = slot / uint32_t(ML), bit = slot % uint32_t(ML);
+  return base[b] + uint32_t(__builtin_popcount(mask[b] & ((1u << bit) - 1u)));
+}
+
+// Second round, for trees of more than kMpCrown chunks: the cells the chunks left are too many for one block (~5 per chunk
+// boundary: 2 500 at N = 10^6), so they get the chunks' treatment once more — blocks of kMpCrown consecutive waiting cells finish
+// those whose waiting descendants all sit in the block, from registers and LDS, and leave the ancestors of their last boundary,
+// one per level at most, to ot_multipole_crown_kernel.  A waiting cell's waiting descendants end at base[subtree end / chunk]: the
+// chunk in which its subtree ends holds no waiting cell of that subtree (it would have to span that chunk's end, which the
+// subtree does not).
+template <typename T, int D>
+__global__ __launch_bounds__(kMpCrown) void ot_multipole_round_kernel(ot_tree<T, D> tree, ot_cell* __restrict__ cells,
+                                                                  uint32_t* __restrict__ lvl_count,
+                                                                  const uint32_t* __restrict__ later0,
+                                                                  const uint32_t* __restrict__ mask0, uint32_t* __restrict__ later1,
+                                                                  uint32_t* __restrict__ mask1, uint32_t max_cells) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  __shared__ T sm[kMpCrown][4];
+  __shared__ uint32_t base[kMpMaxBlocks + 1];
+  __shared__ uint32_t wsum[kMpCrown / 64];
+  __shared__ uint32_t carry_s, mask_s;
+  __shared__ int lvl_hi, lvl_lo;
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  const uint32_t nchunks = (total + kMpChunk - 1) / kMpChunk;
+  if (nchunks <= 1 || nchunks > kMpMaxBlocks) {  // nothing is waiting / (not launched for such trees)
+    if (blockIdx.x == 0 && threadIdx.x == 0) lvl_count[ML + 6] = 0;
+    return;
+  }
+  const uint32_t count   = ot_compact_masks(mask0, nchunks, base, wsum, &carry_s);
+  const uint32_t nblocks = (count + kMpCrown - 1) / kMpCrown;
+  if (blockIdx.x == 0 && threadIdx.x == 0) lvl_count[ML + 6] = nblocks;  // what ot_multipole_crown_kernel compacts
+  if (blockIdx.x >= nblocks) return;
+  const uint32_t k0 = blockIdx.x * kMpCrown, k1 = k0 + kMpCrown < count ? k0 + kMpCrown : count;
+  if (threadIdx.x == 0) {
+    lvl_hi = -1;
+    lvl_lo = ML;
+    mask_s = 0;
   }
   ot_lds_barrier();
-  if (fast) {
+  const uint32_t k = k0 + threadIdx.x;
+  int level = -1;
+  bool wait = false;
+  uint32_t node = 0, r = 0;
+  T cm[NCH], cp[NCH][D];
+  uint32_t slot[NCH];
+  if (k < k1) {
+    r                = ot_compact_item<ML>(k, base, nchunks, mask0, later0);
+    const ot_cell cl = cells[r];
+    uint32_t crank[NCH];
+#pragma unroll
+    for (uint32_t c = 0; c < NCH; ++c) {
+      const ot_node<T> ch = tree.groups[r].load(c);
+      cm[c] = ch.m;
+#pragma unroll
+      for (int q = 0; q < D; ++q) cp[c][q] = ch.p[q];
+      crank[c] = ch.fc < kOtBody && int(cl.start) + 1 < ML ? ch.fc : kMpNone;
+    }
+    node  = cl.node;
+    level = int(cl.start);
+    const uint32_t endchunk = cl.end / kMpChunk < nchunks ? cl.end / kMpChunk : nchunks;
+    wait = base[endchunk] > k1;  // some of its waiting descendants belong to a later block
+    if (wait) {
+      atomicOr(&mask_s, 1u << level);
+      later1[blockIdx.x * uint32_t(ML) + uint32_t(level)] = r;
+      cells[r].rank = kMpLater | kMpLater2 | (blockIdx.x * uint32_t(ML) + uint32_t(level));
+    } else {
+#pragma unroll
+      for (uint32_t c = 0; c < NCH; ++c) {  // a child cell is either finished (by a chunk) or waiting in this block too
+        slot[c] = kMpNone;
+        if (crank[c] != kMpNone) {
+          const uint32_t mark = cells[crank[c]].rank;  // (this block alone may change the marks of this cell's descendants)
+          if (mark & kMpLater) slot[c] = ot_compact_slot(mark & ~(kMpLater | kMpLater2), ML, base, mask0) - k0;
+        }
+      }
+    }
+  }
+  {
+    int wmax = level >= 0 && !wait ? level : -1, wmin = level >= 0 && !wait ? level : ML;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const int a = __shfl_xor(wmax, off, 64), b = __shfl_xor(wmin, off, 64);
+      wmax = a > wmax ? a : wmax;
+      wmin = b < wmin ? b : wmin;
+    }
+    if ((threadIdx.x & 63u) == 0 && wmax >= 0) {
+      atomicMax(&lvl_hi, wmax);
+      atomicMin(&lvl_lo, wmin);
+    }
+  }
+  ot_lds_barrier();
+  const int hi = lvl_hi, lo = lvl_lo;
+  if (threadIdx.x == 0) mask1[blockIdx.x] = mask_s;
+  for (int l = hi; l >= lo; --l) {
+    if (level == l && !wait) {
+      T mass, com[D];
+      ot_multipole_from_registers<T, D>(cm, cp, slot, sm, mass, com);
+      ot_node<T> pn;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) pn.p[q] = T(0);
+#pragma unroll
+      for (int q = 0; q < D; ++q) pn.p[q] = com[q];
+      pn.m   = mass;
+      pn.lvl = uint32_t(level);
+      pn.fc  = 1u + r * NCH;
+      tree.put(node, pn);
+      sm[threadIdx.x][0] = mass;
+#pragma unroll
+      for (int q = 0; q < D; ++q) sm[threadIdx.x][1 + q] = com[q];
+    }
+    ot_lds_barrier();
+  }
+}
+
+// One block finishes what is left: the waiting cells of the chunks (`nprev` < 0: as many blocks as the tree has chunks; pending
+// children carry kMpLater) or those of ot_multipole_round_kernel (`nprev` >= 0: lvl_count[ML + 6] blocks; pending children carry
+// kMpLater2), deepest level first.  Up to kMpCrown of them: compacted, one per thread, from registers and LDS as above.  More (a
+// pathological tree): level by level, children read from memory.
+template <typename T, int D>
+__global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                                  const uint32_t* __restrict__ lvl_count,
+                                                                  const uint32_t* __restrict__ later,
+                                                                  const uint32_t* __restrict__ later_mask, uint32_t max_cells,
+                                                                  int after_round) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  __shared__ T sm[kMpCrown][4];
+  __shared__ uint32_t base[kMpMaxBlocks + 1];
+  __shared__ uint32_t wsum[kMpCrown / 64];
+  __shared__ uint32_t carry_s;
+  __shared__ int lvl_hi;
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  const uint32_t nblocks  = after_round ? lvl_count[ML + 6] : (total + kMpChunk - 1) / kMpChunk;
+  const uint32_t pending  = after_round ? kMpLater2 : kMpLater;
+  if (nblocks <= 1 || nblocks > kMpMaxBlocks) return;  // (a single block leaves nothing)
+  const uint32_t count = ot_compact_masks(later_mask, nblocks, base, wsum, &carry_s);
+  if (threadIdx.x == 0) lvl_hi = -1;
+  ot_lds_barrier();
+  if (count <= uint32_t(kMpCrown)) {
     int level = -1;
     uint32_t node = 0, r = 0;
     T cm[NCH], cp[NCH][D];
     uint32_t slot[NCH];
     if (threadIdx.x < count) {
-      uint32_t b = 0, hi_b = nchunks;  // the chunk whose cells include compact position threadIdx.x: last b with base[b] <= it
-      while (hi_b - b > 1) {
-        const uint32_t mid = b + (hi_b - b) / 2;
-        if (base[mid] <= threadIdx.x) b = mid;
-        else hi_b = mid;
-      }
-      uint32_t m = maskl[b];
-      for (uint32_t skip = threadIdx.x - base[b]; skip > 0; --skip) m &= m - 1u;  // its (skip+1)-th set bit
-      const uint32_t lvl_bit = uint32_t(__builtin_ctz(m));
-      r                      = later[b * uint32_t(ML) + lvl_bit];
-      const ot_cell cl       = cells[r];
-      node                   = cl.node;
-      level                  = int(cl.start);
+      r                = ot_compact_item<ML>(threadIdx.x, base, nblocks, later_mask, later);
+      const ot_cell cl = cells[r];
+      node             = cl.node;
+      level            = int(cl.start);
       uint32_t crank[NCH];
 #pragma unroll
       for (uint32_t c = 0; c < NCH; ++c) {
@@ -1260,14 +1400,11 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T,
         crank[c] = ch.fc < kOtBody && level + 1 < ML ? ch.fc : kMpNone;
       }
 #pragma unroll
-      for (uint32_t c = 0; c < NCH; ++c) {  // a child cell is either finished (by a chunk) or waiting here too
+      for (uint32_t c = 0; c < NCH; ++c) {  // a child cell is either finished already or waiting here too
         slot[c] = kMpNone;
         if (crank[c] != kMpNone) {
           const uint32_t mark = cells[crank[c]].rank;
-          if (mark & kMpLater) {
-            const uint32_t sl = mark & ~kMpLater, cb = sl / uint32_t(ML), cl_bit = sl % uint32_t(ML);
-            slot[c] = base[cb] + uint32_t(__builtin_popcount(maskl[cb] & ((1u << cl_bit) - 1u)));
-          }
+          if (mark & pending) slot[c] = ot_compact_slot(mark & ~(kMpLater | kMpLater2), ML, base, later_mask);
         }
       }
       atomicMax(&lvl_hi, level);
@@ -1294,28 +1431,14 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T,
     }
     return;
   }
-  // many chunks: each level's waiting cells straight from the slots (a thread keeps the masks of its first chunks in registers)
-  constexpr int PER = 8;
-  uint32_t masks[PER];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const uint32_t b = threadIdx.x + uint32_t(j) * uint32_t(kMpCrown);
-    masks[j]         = b < nchunks ? later_mask[b] : 0u;
-    if (masks[j]) atomicMax(&lvl_hi, 31 - __builtin_clz(masks[j]));
-  }
-  for (uint32_t b = threadIdx.x + PER * uint32_t(kMpCrown); b < nchunks; b += kMpCrown) {
+  // more waiting cells than threads: each level's straight from the slots
+  for (uint32_t b = threadIdx.x; b < nblocks; b += kMpCrown) {
     const uint32_t m = later_mask[b];
     if (m) atomicMax(&lvl_hi, 31 - __builtin_clz(m));
   }
   __syncthreads();
   for (int l = lvl_hi; l >= 0; --l) {
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
-      if ((masks[j] >> l) & 1u) {
-        const uint32_t b = threadIdx.x + uint32_t(j) * uint32_t(kMpCrown);
-        ot_multipole_cell<T, D>(tree, cells[later[b * uint32_t(ML) + uint32_t(l)]].node);
-      }
-    for (uint32_t b = threadIdx.x + PER * uint32_t(kMpCrown); b < nchunks; b += kMpCrown)
+    for (uint32_t b = threadIdx.x; b < nblocks; b += kMpCrown)
       if ((later_mask[b] >> l) & 1u) ot_multipole_cell<T, D>(tree, cells[later[b * uint32_t(ML) + uint32_t(l)]].node);
     __threadfence_block();
     __syncthreads();  // (waits for the stores: the next level reads them back)
@@ -2183,6 +2306,7 @@ struct nbody_octree {
   uint32_t* bhist       = nullptr;  //   per-block cells per level
   uint32_t* later       = nullptr;  //   ranks left to ot_multipole_crown_kernel: slot (chunk, level)
   uint32_t* later_mask  = nullptr;  //   per chunk: the levels whose slot is in use
+  uint32_t* later2 = nullptr, *later2_mask = nullptr;  //   the same for the blocks of ot_multipole_round_kernel
   uint32_t* lvl_count = nullptr;  // [MAXL + 2] level counts and deep groups, flags, two barrier counters, deep-list cursor, crown count
   uint32_t* counters = nullptr;
   int sorted_buf   = 0;
@@ -2286,7 +2410,8 @@ template <typename T, int D>
 static int ot_tree_run(nbody_octree* t, hipStream_t st) {
   constexpr uint32_t NCH = 1u << D;
   const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
-  if ((t->build == 0 || t->build == 3) && (t->max_cells + kMpChunk - 1) / kMpChunk > uint32_t(kMpCrown)) {
+  const uint32_t max_chunks = (t->max_cells + kMpChunk - 1) / kMpChunk;
+  if ((t->build == 0 || t->build == 3) && max_chunks > kMpMaxBlocks) {  // beyond 4.2 * 10^6 bodies: one launch per level over all ranks
     for (int l = kMaxLevels<D> - 1; l >= 0; --l) {
       hipLaunchKernelGGL((ot_multipole_ranks_level_kernel<T, D>), dim3((t->max_cells + kOB - 1) / kOB), dim3(kOB), 0, st, l, tree,
                          t->cells, t->lvl_count, t->capacity, t->max_cells);
@@ -2294,12 +2419,19 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
     }
     return NBODY_OK;
   }
-  if (t->build == 0 || t->build == 3) {  // rank chunks, then the cells that span chunk boundaries
-    hipLaunchKernelGGL((ot_multipole_chunks_kernel<T, D>), dim3((t->max_cells + kMpChunk - 1) / kMpChunk), dim3(kMpChunk), 0, st, tree,
-                       t->cells, t->lvl_count, t->later, t->later_mask, t->capacity, t->max_cells);
+  if (t->build == 0 || t->build == 3) {  // rank chunks, then the cells that span chunk boundaries: in one block, or in two rounds
+    hipLaunchKernelGGL((ot_multipole_chunks_kernel<T, D>), dim3(max_chunks), dim3(kMpChunk), 0, st, tree, t->cells, t->lvl_count,
+                       t->later, t->later_mask, t->capacity, t->max_cells);
     NB_HIP(hipGetLastError());
-    hipLaunchKernelGGL((ot_multipole_crown_kernel<T, D>), dim3(1), dim3(kMpCrown), 0, st, tree, t->cells, t->lvl_count, t->later,
-                       t->later_mask, t->max_cells);
+    const bool rounds = max_chunks > uint32_t(kMpCrown);  // (decided by the size the tree was created for: the launches are recorded)
+    if (rounds) {
+      const uint32_t blocks = (max_chunks * uint32_t(kMaxLevels<D>) + kMpCrown - 1) / kMpCrown;
+      hipLaunchKernelGGL((ot_multipole_round_kernel<T, D>), dim3(blocks), dim3(kMpCrown), 0, st, tree, t->cells, t->lvl_count, t->later,
+                         t->later_mask, t->later2, t->later2_mask, t->max_cells);
+      NB_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL((ot_multipole_crown_kernel<T, D>), dim3(1), dim3(kMpCrown), 0, st, tree, t->cells, t->lvl_count,
+                       rounds ? t->later2 : t->later, rounds ? t->later2_mask : t->later_mask, t->max_cells, rounds ? 1 : 0);
     NB_HIP(hipGetLastError());
     return NBODY_OK;
   }
@@ -2465,6 +2597,11 @@ extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, ui
     NB_ALLOC(t->bhist, sizeof(uint32_t) * nblk * size_t(maxl + 1));
     NB_ALLOC(t->later, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2) * size_t(maxl));
     NB_ALLOC(t->later_mask, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2));
+    {
+      const size_t blocks2 = ((size_t(t->max_cells) / kMpChunk + 2) * size_t(maxl) + kMpCrown - 1) / kMpCrown + 1;
+      NB_ALLOC(t->later2, sizeof(uint32_t) * blocks2 * size_t(maxl));
+      NB_ALLOC(t->later2_mask, sizeof(uint32_t) * blocks2);
+    }
   }
 #undef NB_ALLOC
   if (hipError_t e = hipMemset(t->lvl_count, 0, sizeof(uint32_t) * size_t(maxl + 8)); e != hipSuccess) return fail(e, "hipMemset");
@@ -2497,6 +2634,8 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
   (void)hipFree(t->bhist);
   (void)hipFree(t->later);
   (void)hipFree(t->later_mask);
+  (void)hipFree(t->later2);
+  (void)hipFree(t->later2_mask);
   (void)hipFree(t->lvl_count);
   (void)hipFree(t->counters);
   delete t;

@@ -325,6 +325,22 @@ def test_octree_errors(nb):
         d2.octree.compute_force(d2.state(), 0.5, d2.stream)
 
 
+def test_octree_one_pass_build_beyond_the_round_limit(nb):
+    """Above 4.2 * 10^6 cells the one-pass build's multipole pass takes one launch per level over all ranks (the compacted lists
+    of its rounds no longer fit a block's LDS).  4.3 * 10^6 bodies in float: the same tree size, root monopole and accelerations
+    as the breadth-first build, bit for bit."""
+    n = 4300000
+    res = []
+    for form in (1, 3):
+        dev = nb.DeviceSystem.from_host(nb.build_model(0, 3, "galaxy", n))
+        dev.octree.set_build(form)
+        dev.octree_force(0.7)
+        dev.sync()
+        res.append((dev.octree.info(dev.stream), dev.download().a.copy()))
+        dev.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+
+
 @pytest.mark.parametrize("dtype", [1, 0])
 def test_octree_build_forms_over_many_steps(nb, dtype):
     """Sixty recorded-and-replayed steps of an evolving galaxy: the one-pass build reuses its lists, marks and masks from step to
@@ -615,7 +631,7 @@ def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
     tree; in the one-pass build one position starts 20 cells), for two and three bodies, and for sizes around the 1024-position
     blocks of the prefix sum."""
     cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2), ("uniform", 1), ("uniform", 3), ("uniform", 1023), ("uniform", 1024),
-             ("uniform", 1025), ("galaxy", 2049)]
+             ("uniform", 1025), ("galaxy", 2049), ("galaxy", 300000)]   # 300 000: the multipole pass takes its second round
     if dim == 3:
         cases.append(("plummer", 5000))
     for wl, n in cases:

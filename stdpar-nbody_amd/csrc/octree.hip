@@ -852,15 +852,6 @@ __device__ __forceinline__ uint32_t ot_first_true(const uint64_t* __restrict__ s
   return a + falses;
 }
 
-// The levels whose cells get lane groups of their own (extra blocks of ot_build_lcp_kernel).  A position that starts a top-level
-// cell usually starts the nested first children below it as well — position 0 starts one cell per level down to the first split —
-// and each of those is a big cell with its searches: in the position loop that was ONE lane group working for 40 us while the
-// average wave takes 6 (N = 10^5).  1 + 2^D + ... cells: 585 in 3D, 341 in 2D.
-template <int D>
-constexpr int kTopLevels = D == 3 ? 4 : 5;
-template <int D>
-constexpr uint32_t kTopCells = D == 3 ? 585u : 341u;
-
 template <typename T, int D>
 struct ot_lcp_args {
   const uint64_t* skeys;
@@ -869,6 +860,7 @@ struct ot_lcp_args {
   const int8_t* lv;
   const uint32_t* plocal;
   const uint32_t* bbase;
+  const uint32_t* rankpos;
   const T* m;
   const T* x;
   ot_tree<T, D> tree;
@@ -998,37 +990,39 @@ __device__ __forceinline__ bool ot_lcp_cell(const ot_lcp_args<T, D>& g, uint32_t
   return true;
 }
 
-// Blocks [0, position_blocks): 2^D lanes per sorted position build the cells below the top levels that start there, shallowest
-// first.  The blocks behind them: 2^D lanes per possible top-level cell (level, prefix) find its range in the sorted keys and,
-// if it holds >= 2 bodies, build it.
+// rank -> the sorted position its cell starts at (the level follows from the rank: d = l_i + 1 + rank - P[i]).  With this map every
+// cell has lane groups of its own.  Mapping lane groups to POSITIONS instead left more than half of the waves with nothing to do
+// (N = 10^6: 125 000 waves, 185 us) and made one group walk through all the cells that start at its position — position 0 starts one
+// nested big cell per level from the root down, 40 us of searches in one lane group while the average wave took 6.
+template <int D>
+__global__ __launch_bounds__(kOB) void ot_lcp_scatter_kernel(uint32_t n, const int8_t* __restrict__ lv, const uint32_t* __restrict__ plocal,
+                                                             const uint32_t* __restrict__ bbase, uint32_t* __restrict__ rankpos,
+                                                             uint32_t max_cells) {
+  const uint32_t i = blockIdx.x * kOB + threadIdx.x;
+  if (i >= n) return;
+  const int li = lv[i], ln = lv[i + 1];
+  if (ln <= li) return;
+  const uint32_t r0 = bbase[i / kLcpB] + plocal[i];
+  for (int q = 0; q < ln - li; ++q)
+    if (r0 + uint32_t(q) < max_cells) rankpos[r0 + uint32_t(q)] = i;
+}
+
+// 2^D lanes per cell, by rank
 template <typename T, int D>
-__global__ __launch_bounds__(kLcpBuildB) void ot_build_lcp_kernel(ot_lcp_args<T, D> g, uint32_t position_blocks) {
+__global__ __launch_bounds__(kLcpBuildB) void ot_build_lcp_kernel(ot_lcp_args<T, D> g) {
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
-  constexpr int TOP      = kTopLevels<D>;
-  const uint32_t c = threadIdx.x % NCH;
-  if (blockIdx.x >= position_blocks) {
-    uint32_t q = ((blockIdx.x - position_blocks) * kLcpBuildB + threadIdx.x) / NCH;  // which top cell
-    if (q >= kTopCells<D>) return;
-    int d = 0;
-    for (uint32_t width = 1; q >= width; width *= NCH) {  // level d has 2^(D d) prefixes
-      q -= width;
-      ++d;
-    }
-    uint32_t s = 0, e = g.n;
-    if (d > 0) {
-      const int psh = D * (ML - d);
-      s = ot_first_true(g.skeys, 0u, g.n, [&](uint64_t k) { return (k >> psh) >= uint64_t(q); });
-      e = ot_first_true(g.skeys, s, g.n, [&](uint64_t k) { return (k >> psh) > uint64_t(q); });
-    }
-    if (e - s >= 2) ot_lcp_cell<T, D>(g, s, d, int(g.lv[s]), c, e);
-    return;
-  }
-  const uint32_t i = (blockIdx.x * kLcpBuildB + threadIdx.x) / NCH;
-  if (i >= g.n) return;  // (whole lane groups)
-  const int li = g.lv[i], ln = g.lv[i + 1];
-  for (int d = li + 1 > TOP ? li + 1 : TOP; d <= ln && d < ML; ++d)
-    if (!ot_lcp_cell<T, D>(g, i, d, li, c, 0u)) break;  // (deeper cells have higher ranks)
+  uint32_t total = 0;
+#pragma unroll
+  for (int l = 0; l <= ML; ++l) total += g.lvl_count[l];
+  if (total > g.max_cells) total = g.max_cells;
+  const uint32_t r = (blockIdx.x * kLcpBuildB + threadIdx.x) / NCH, c = threadIdx.x % NCH;
+  if (r >= total) return;  // (whole lane groups; whole blocks beyond the tree's cells)
+  const uint32_t i = g.rankpos[r];
+  const int li = g.lv[i];
+  const int d  = li + 1 + int(r - (g.bbase[i / kLcpB] + g.plocal[i]));
+  if (d >= ML) return;  // a cell at the key depth: its parent hands it to ot_build_deep_kernel
+  ot_lcp_cell<T, D>(g, i, d, li, c, 0u);
 }
 
 template <typename T, int D>
@@ -2304,6 +2298,7 @@ struct nbody_octree {
   uint32_t* plocal      = nullptr;  //   block-local exclusive prefix of the cells starting at each position
   uint32_t* bsum        = nullptr;  //   per-block sums -> bases
   uint32_t* bhist       = nullptr;  //   per-block cells per level
+  uint32_t* rankpos     = nullptr;  //   rank -> sorted position its cell starts at
   uint32_t* later       = nullptr;  //   ranks left to ot_multipole_crown_kernel: slot (chunk, level)
   uint32_t* later_mask  = nullptr;  //   per chunk: the levels whose slot is in use
   uint32_t* later2 = nullptr, *later2_mask = nullptr;  //   the same for the blocks of ot_multipole_round_kernel
@@ -2356,12 +2351,14 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
     hipLaunchKernelGGL((ot_lcp_finish_kernel<T, D>), dim3(1), dim3(1024), 0, st, n, nblk, t->bsum, t->bhist,
                        static_cast<const T*>(s->m), static_cast<const T*>(s->x), tree, t->lvl_count);
     NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL((ot_lcp_scatter_kernel<D>), dim3((n + kOB - 1) / kOB), dim3(kOB), 0, st, n, t->lcp, t->plocal, t->bsum, t->rankpos,
+                       t->max_cells);
+    NB_HIP(hipGetLastError());
     {
-      const ot_lcp_args<T, D> args{t->keys[fin], t->idx[fin], n, t->lcp, t->plocal, t->bsum, static_cast<const T*>(s->m),
+      const ot_lcp_args<T, D> args{t->keys[fin], t->idx[fin], n, t->lcp, t->plocal, t->bsum, t->rankpos, static_cast<const T*>(s->m),
                                    static_cast<const T*>(s->x), tree, t->cells, t->tops, t->lvl_count, flags, t->capacity, t->max_cells};
-      const uint32_t position_blocks = uint32_t((uint64_t(n) * NCH + kLcpBuildB - 1) / kLcpBuildB);
-      const uint32_t top_blocks      = (kTopCells<D> * NCH + kLcpBuildB - 1) / kLcpBuildB;
-      hipLaunchKernelGGL((ot_build_lcp_kernel<T, D>), dim3(position_blocks + top_blocks), dim3(kLcpBuildB), 0, st, args, position_blocks);
+      const uint32_t blocks = uint32_t((uint64_t(t->max_cells) * NCH + kLcpBuildB - 1) / kLcpBuildB);
+      hipLaunchKernelGGL((ot_build_lcp_kernel<T, D>), dim3(blocks), dim3(kLcpBuildB), 0, st, args);
       NB_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
@@ -2595,6 +2592,7 @@ extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, ui
     NB_ALLOC(t->plocal, sizeof(uint32_t) * (size_t(n) + 1));
     NB_ALLOC(t->bsum, sizeof(uint32_t) * nblk);
     NB_ALLOC(t->bhist, sizeof(uint32_t) * nblk * size_t(maxl + 1));
+    NB_ALLOC(t->rankpos, sizeof(uint32_t) * size_t(t->max_cells));
     NB_ALLOC(t->later, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2) * size_t(maxl));
     NB_ALLOC(t->later_mask, sizeof(uint32_t) * (size_t(t->max_cells) / kMpChunk + 2));
     {
@@ -2632,6 +2630,7 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
   (void)hipFree(t->plocal);
   (void)hipFree(t->bsum);
   (void)hipFree(t->bhist);
+  (void)hipFree(t->rankpos);
   (void)hipFree(t->later);
   (void)hipFree(t->later_mask);
   (void)hipFree(t->later2);

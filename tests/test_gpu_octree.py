@@ -357,7 +357,7 @@ def test_octree_build_forms_over_many_steps(nb, dtype):
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
 
-@pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2)])
+@pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2), (0, 2)])
 def test_octree_build_forms_fuzz(nb, dtype, dim):
     """The one-pass build against the breadth-first one on geometry that random clouds do not produce: bodies exactly on cell
     boundaries (grid-aligned coordinates: `pos > divide` is false on the boundary), on a line, on a plane, in tight clusters with
@@ -412,6 +412,18 @@ def test_octree_build_forms_fuzz(nb, dtype, dim):
             assert res[0][0] == r[0], (case, n, kind, res[0][0], r[0])
             if res[0][0][0] != "refused":
                 assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]), (case, n, kind)
+        if res[0][0][0] != "refused":
+            walks = []
+            for walk in (1, 2):   # the compiler-scheduled walk and the visit round written as ISA, on the same degenerate tree
+                dev = nb.DeviceSystem.from_host(hs)
+                dev.octree.set_walk(walk)
+                dev.octree.enable_counters(True)
+                dev.octree_force(0.4)
+                dev.sync()
+                walks.append((dev.octree.read_counters(dev.stream).copy(), dev.download().a.copy()))
+                dev.close()
+            assert np.array_equal(walks[0][0], walks[1][0]) and np.array_equal(walks[0][1], walks[1][1]), (case, n, kind, "walk forms")
+            assert np.array_equal(walks[0][1], res[0][2]), (case, n, kind)
 
 
 @pytest.mark.parametrize("form", [3, 1, 4, 2])

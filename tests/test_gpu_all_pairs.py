@@ -591,6 +591,62 @@ def test_near_pairs_in_another_source_tile(nb, oracle, dtype, dim, extreme):
     dev.close()
 
 
+@pytest.mark.parametrize("dim", [3, 2])
+def test_sparse_system_pair_rules_with_planted_pairs(nb, oracle, dim):
+    """K1's launch-level far mode (double, >= 32 768 bodies whose bounding box says "sparse"): pairs at r^2 >= 4 drop the eps term
+    of the weight, a batch that holds a closer pair selects per lane, r^2 < 2^-16 takes the guarded form.  40 000 bodies in a box
+    of 2 * 10^6 (3D) / 6 * 10^6 (2D) units of volume, with partners planted tiles apart from their targets: r^2 EXACTLY 4 and one
+    ulp to either side, gaps from 1.5 down to 1e-12, coincident bodies, a zero-mass partner, a denormal r^2.  Every target against
+    the oracle relative to its own scale; then the same launch over shard windows, bit for bit (the rule a pair takes depends on its
+    own r^2 only, never on its batch)."""
+    rng = np.random.default_rng(77 + dim)
+    n = 40000
+    hs = nb.HostSystem(1, dim, n)
+    side = 63.0 if dim == 3 else 1250.0
+    hs.x[:] = rng.uniform(-side, side, (n, dim))
+    hs.m[:] = rng.uniform(0.5, 2.0, n)
+    gaps = [2.0, np.nextafter(2.0, 3.0), np.nextafter(2.0, 1.0), 1.5, 0.3, 2.0 ** -8, np.nextafter(2.0 ** -8, 0.0), 3e-3, 1e-6, 1e-12]
+    planted = []
+    for k, gap in enumerate(gaps):
+        i, j = 101 + 977 * k, 101 + 977 * k + 4099 + 1033 * k   # another source tile, another slice, usually another chunk
+        d = np.zeros(dim)
+        d[k % dim] = gap
+        hs.x[i] = np.round(hs.x[i])          # exact coordinates: the planted r^2 is what it says
+        hs.x[j] = hs.x[i] + d
+        planted += [i, j]
+    hs.x[300] = hs.x[29000]                  # coincident, distinct bodies
+    hs.x[400] = 0
+    hs.x[31000] = 0
+    hs.x[31000, 0] = 1e-160                  # r^2 = 1e-320: denormal
+    hs.x[500] = hs.x[24000]
+    hs.x[500, dim - 1] += 1e-3
+    hs.m[500] = 0                            # zero-mass partner of a near pair
+    planted += [300, 29000, 400, 31000, 500, 24000]
+    planted = np.array(planted)
+    hs.c, hs.dt = 1.0, 0.01
+    dev = nb.DeviceSystem.from_host(hs)
+    assert "sparse" in nb.describe_all_pairs(dev.state()) or "far" in nb.describe_all_pairs(dev.state())
+    dev.all_pairs_force()
+    dev.sync()
+    a = dev.download().a.astype(np.float64)
+    assert np.all(np.isfinite(a))
+    ref = _as_oracle_state(oracle, hs)
+    oracle.all_pairs_force(ref)
+    ra = ref.a.astype(np.float64)
+    mag = np.abs(ra).max(axis=1)
+    floor = np.median(mag)
+    err = np.abs(a - ra).max(axis=1)
+    bad = np.where(err > 2e-13 * np.maximum(mag, floor))[0]
+    assert bad.size == 0, (bad[:6], err[bad[:6]], mag[bad[:6]])
+    assert np.all(err[planted] <= 2e-13 * np.maximum(mag[planted], floor))
+    for first, count in ((0, n // 8), (n // 8, n // 8), (n - 5000, 5000), (12345, 7777)):
+        dev.all_pairs_force(first, count)
+        dev.sync()
+        w = dev.download().a[first:first + count]
+        assert np.array_equal(w, a[first:first + count].astype(w.dtype)), (first, count)
+    dev.close()
+
+
 def test_config2_as_written_100_steps(nb, oracle):
     """BASELINE config[1] as written: `-n 65536 -s 100 --precision double --algorithm all-pairs` — no workload flag, so the
     reference's default, uniform (src/arguments.h:27) — 100 steps of K1 + K3 (src/all_pairs.h:86-97).  The oracle cannot run

@@ -147,6 +147,89 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
 }
 
 
+// A sort that fits ONE block's tile (n <= 2048: the reference's default run is 1000 bodies) does all its passes in one launch: the
+// block's own digit counts are the whole histogram, and a block barrier separates the passes (the pairs ping-pong through the
+// same two global buffers; a block's stores are visible to its own later loads).  16 dependent launches were half of the octree
+// step at that size.
+static __global__ __launch_bounds__(kSortB) void radix_sort_one_block_kernel(uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
+                                                                             uint32_t* __restrict__ i0, uint32_t* __restrict__ i1,
+                                                                             uint32_t n, int key_bits) {
+  __shared__ uint32_t wcnt[kSortB / 64][256];
+  __shared__ uint32_t dbase[256], dtot[256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+  int pass = 0;
+  for (int shift = 0; shift < key_bits; shift += 8, ++pass) {
+    const uint64_t* kin  = (pass & 1) ? k1 : k0;
+    uint64_t* kout       = (pass & 1) ? k0 : k1;
+    const uint32_t* iin  = pass == 0 ? nullptr : ((pass & 1) ? i1 : i0);  // first pass: payload = position
+    uint32_t* iout       = (pass & 1) ? i0 : i1;
+    for (int q = threadIdx.x; q < (kSortB / 64) * 256; q += kSortB) (&wcnt[0][0])[q] = 0;
+    __syncthreads();
+    uint64_t key[kSortIPT];
+    uint32_t pay[kSortIPT], rank[kSortIPT];
+#pragma unroll
+    for (int s = 0; s < kSortIPT; ++s) {
+      const uint32_t i = wave * (64 * kSortIPT) + s * 64 + lane;
+      const bool valid = i < n;
+      key[s]           = valid ? kin[i] : 0ull;
+      pay[s]           = valid ? (iin ? iin[i] : i) : 0u;
+      const uint32_t d = uint32_t(key[s] >> shift) & 255u;
+      uint64_t same    = __ballot(valid);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const bool bit      = (d >> b) & 1u;
+        const uint64_t vote = __ballot(valid && bit);
+        same &= bit ? vote : ~vote;
+      }
+      const uint32_t before = __popcll(same & lt_mask);
+      const uint32_t base   = wcnt[wave][d];
+      rank[s]               = base + before;
+      __builtin_amdgcn_wave_barrier();
+      if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    {  // digit = threadIdx.x: its total over the waves, then the exclusive scan over the digits
+      uint32_t v = 0;
+#pragma unroll
+      for (int w = 0; w < kSortB / 64; ++w) v += wcnt[w][threadIdx.x];
+      dtot[threadIdx.x] = v;
+      uint32_t inc      = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        uint32_t o = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += o;
+      }
+      dbase[threadIdx.x] = inc - v;
+    }
+    __syncthreads();
+    {
+      uint32_t run = dbase[threadIdx.x];
+      for (int w = 0; w < wave; ++w) run += dbase[w * 64 + 63] + dtot[w * 64 + 63];  // totals of the earlier 64-digit groups
+#pragma unroll
+      for (int w = 0; w < kSortB / 64; ++w) {
+        uint32_t cw          = wcnt[w][threadIdx.x];
+        wcnt[w][threadIdx.x] = run;
+        run += cw;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < kSortIPT; ++s) {
+      const uint32_t i = wave * (64 * kSortIPT) + s * 64 + lane;
+      if (i < n) {
+        const uint32_t d   = uint32_t(key[s] >> shift) & 255u;
+        const uint32_t pos = wcnt[wave][d] + rank[s];
+        kout[pos]          = key[s];
+        iout[pos]          = pay[s];
+      }
+    }
+    __threadfence_block();
+    __syncthreads();  // the next pass reads what this one wrote
+  }
+}
+
 // hist needs 256 * (nblk + 1) u32, nblk = radix_sort_blocks(n).  Sorts by key bits [0, key_bits): the pairs start in
 // (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.
 inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
@@ -164,6 +247,12 @@ constexpr uint32_t kSortFusedBlocks = 16;  // up to 32 768 keys: every block sca
 inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int key_bits, uint32_t* hist, hipStream_t st,
                             int* final_buf) {
   const uint32_t nblk    = radix_sort_blocks(n);
+  if (nblk == 1) {
+    hipLaunchKernelGGL(radix_sort_one_block_kernel, dim3(1), dim3(kSortB), 0, st, keys[0], keys[1], idx[0], idx[1], n, key_bits);
+    NB_HIP(hipGetLastError());
+    *final_buf = ((key_bits + 7) / 8) & 1;
+    return NBODY_OK;
+  }
   int cur                = 0;
   const uint32_t* idx_in = nullptr;  // first pass: payload = position
   for (int shift = 0; shift < key_bits; shift += 8) {

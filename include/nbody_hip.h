@@ -151,8 +151,15 @@ int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, double theta, vo
  * what: 0 keys u64[n] (pre-sort order) | 1 perm u32[n] (new -> old) | 2 node monopoles T[nnodes][D+1]
  * (x..., mass) | 3 node widths T[nnodes] | 4 node boxes T[nnodes][2D] | 5 traversal counters
  * u32[n][4] {node tests, leaf visits, monopole terms, body terms} (filled by
- * nbody_bvh_compute_force only after nbody_bvh_enable_counters(t, 1)). */
+ * nbody_bvh_compute_force only after nbody_bvh_enable_counters(t, 1)) | 6 opening thresholds T[nnodes]: the largest v
+ * with width^2 >= fl(theta^2 * d2) for every d2 <= v, i.e. the reference's test width^2 < theta^2 * d2
+ * (src/bvh.h:246-248) is v < d2 bit for bit; written by the build for the angle of the last nbody_bvh_compute_force
+ * (0.5, the reference's default, before the first) and rewritten by a traversal that asks for another one. */
 int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream);
+/* The thresholds of what = 6 for given width^2 values, computed on the HOST by the same function the build kernels run (no
+ * device needed): out[i] = the largest v such that width2[i] < fl(theta^2 * d2) fails for every d2 <= v; -1 for a negative
+ * input (body entries), +inf when no distance accepts.  For the tests that hold this form against src/bvh.h:246-248. */
+int nbody_bvh_opening_thresholds(int dtype, const void* width2, double theta, size_t n, void* out);
 int nbody_bvh_enable_counters(nbody_bvh* t, int on);
 /* K9 scheduling form: 0 = auto, 1 = one independent stackless walk per lane (the reference's loop as is),
  * 2 = wave-cooperative sweep of the union of the wave's walks in DFS key order (3 / 4: the compiler-scheduled step

@@ -182,6 +182,17 @@ def bvh_force(s, tr, theta, want_counts=False):
     return counts
 
 
+def can_approximate(dtype, bw, theta, d2):
+    """bvh.h:246-248 on arrays: bw * bw < theta^2 * d2 in T (theta^2 formed in T, bvh.h:252)."""
+    t = np_dtype(dtype)
+    bw, d2 = np.ascontiguousarray(bw, t), np.ascontiguousarray(d2, t)
+    assert bw.shape == d2.shape
+    out = np.zeros(bw.shape, np.uint8)
+    r = lib().oracle_can_approximate(dtype, _p(bw), C.c_double(theta), _p(d2), C.c_uint64(bw.size), _p(out))
+    assert r == 0
+    return out.astype(bool)
+
+
 def bvh_step_force(s, theta):
     """bbox -> keys -> sort (permutes the state in place) -> build -> traversal (bvh.h:382-393)."""
     r = lib().oracle_bvh_step_force(s.dtype, s.dim, _p(s.m), _p(s.x), _p(s.v), _p(s.a), _p(s.ao), C.c_double(s.c),

@@ -220,6 +220,23 @@ int oracle_bvh_force(int dtype, int dim, const void* m, const void* x, void* a, 
   return 0;
 }
 
+/* bvh.h:246-248 can_approximate on arrays: out[i] = bw[i] * bw[i] < theta^2 * d2[i], in T, with theta^2 = theta * theta in T as
+ * compute_force forms it (bvh.h:252).  Used by the tests of the product's one-compare form of this test. */
+int oracle_can_approximate(int dtype, const void* bw, double theta, const void* d2, uint64_t n, uint8_t* out) {
+  if (dtype == 0) {
+    const float *w = (const float*)bw, *d = (const float*)d2;
+    const float th = (float)theta, th2 = th * th;
+    for (uint64_t i = 0; i < n; ++i) out[i] = w[i] * w[i] < th2 * d[i];
+  } else if (dtype == 1) {
+    const double *w = (const double*)bw, *d = (const double*)d2;
+    const double th2 = theta * theta;
+    for (uint64_t i = 0; i < n; ++i) out[i] = w[i] * w[i] < th2 * d[i];
+  } else {
+    return -1;
+  }
+  return 0;
+}
+
 /* One full bvh force phase as run_bvh does it per step (bvh.h:382-393): bbox, keys+sort (permutes
  * m,x,v,a,ao in place), build, traversal.  Scratch is allocated here. */
 int oracle_bvh_step_force(int dtype, int dim, void* m, void* x, void* v, void* a, void* ao, double c, uint32_t sz,

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
     "nbody_comm_get_unique_id", "nbody_comm_create", "nbody_comm_create_all", "nbody_comm_destroy", "nbody_comm_world",
     "nbody_comm_rank", "nbody_comm_rccl_version", "nbody_shard_range", "nbody_comm_group_begin", "nbody_comm_group_end",
-    "nbody_allgather_positions",
+    "nbody_allgather_positions", "nbody_bvh_opening_thresholds",
 ]
 ABI_MAJOR = 2
 COMM_ID_BYTES = 128
@@ -112,6 +112,15 @@ def np_dtype(dtype):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def bvh_opening_thresholds(dtype, width2, theta):
+    """The opening thresholds nbody_bvh_build_tree stores (nbody_bvh_read what = 6) for given width^2 values, computed on the
+    host by the same function (no device needed)."""
+    w2 = np.ascontiguousarray(width2, np_dtype(dtype))
+    out = np.empty_like(w2)
+    _check(lib().nbody_bvh_opening_thresholds(dtype, _p(w2), C.c_double(theta), C.c_size_t(w2.size), _p(out)))
+    return out
 
 
 def device_info(device=0):
@@ -268,7 +277,8 @@ class Bvh:
     def read(self, what, stream=None):
         t = np_dtype(self.dtype)
         shapes = {0: ((self.n,), np.uint64), 1: ((self.n,), np.uint32), 2: ((self.nnodes, self.dim + 1), t),
-                  3: ((self.nnodes,), t), 4: ((self.nnodes, 2 * self.dim), t), 5: ((self.n, 4), np.uint32)}
+                  3: ((self.nnodes,), t), 4: ((self.nnodes, 2 * self.dim), t), 5: ((self.n, 4), np.uint32),
+                  6: ((self.nnodes,), t)}
         shape, dt = shapes[what]
         out = np.zeros(shape, dt)
         _check(lib().nbody_bvh_read(self.h, what, _p(out), C.c_size_t(out.nbytes), C.c_void_p(stream)))

@@ -21,6 +21,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace nbody {
 
@@ -61,6 +62,8 @@ struct nbody_bvh {
   int final_buf   = 0;  // which idx[] holds the permutation after the sort
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   int launch_order = 0; // sweep: 0 = work items (cut groups first), 1 = one block per group in index order
+  double theta      = 0.5;   // the opening angle the next build writes thresholds for (the last one a traversal was asked for)
+  double th2_built  = -1.0;  // theta^2 (in T) of the thresholds the records hold; -1: none
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
 };
 
@@ -288,10 +291,48 @@ __device__ __forceinline__ T node_width(const T* b) {  // src/bvh.h:140-144, std
   return w;
 }
 
+// The opening test as ONE compare (K9's sweep).  The reference accepts a node iff  w2 < fl(theta^2 * d2)  (src/bvh.h:246-248;
+// w2 = width * width rounded once, the product rounded once).  fl(theta^2 * d2) is monotone non-decreasing in d2 >= 0, so the
+// set of distances that accept is an up-set of the doubles: with dmin its smallest member (found below by bisection on the bit
+// pattern, which orders non-negative floating-point numbers) and v the number just below dmin,
+//     w2 < fl(theta^2 * d2)   <=>   v < d2        for every d2 >= 0,
+// bit for bit and for every theta — the record carries v (slot D + 3), and the sweep tests !(v >= d2), which like the product
+// form accepts a NaN distance.  No distance accepts (theta = 0, w2 = inf): v = +inf.  Body entries carry -1 (always accepted),
+// a NaN width stays NaN (always accepted, as !(NaN >= x) was).  The product is evaluated here exactly as the per-lane form and
+// the reference evaluate it: one multiply in T, no contraction.
+template <typename T>
+__host__ __device__ __forceinline__ T open_threshold(T w2, T th2) {
+#pragma clang fp contract(off)
+  using U = typename std::conditional<sizeof(T) == 8, unsigned long long, uint32_t>::type;
+  constexpr U kInf = sizeof(T) == 8 ? U(0x7ff0000000000000ull) : U(0x7f800000u);
+  if (w2 < T(0)) return T(-1);
+  if (!(w2 == w2)) return w2;
+  auto accepts = [&](U bits) { return w2 < th2 * __builtin_bit_cast(T, bits); };
+  if (!accepts(kInf)) return __builtin_bit_cast(T, kInf);
+  U lo = 0, hi = kInf;  // !accepts(lo) (theta^2 * 0 = 0 <= w2), accepts(hi)
+  const T q = w2 / th2;  // dmin is within a few ulps of the quotient unless the product leaves the normal range
+  if (q == q && q < __builtin_bit_cast(T, kInf)) {
+    const U qb = __builtin_bit_cast(U, q);
+    const U a = qb > U(8) ? qb - U(8) : U(0), b = qb + U(8) < kInf ? qb + U(8) : kInf;
+    if (accepts(a)) hi = a;
+    else lo = a;
+    if (b < hi) {
+      if (accepts(b)) hi = b;
+      else lo = b;
+    }
+  }
+  while (hi - lo > U(1)) {
+    const U mid = lo + (hi - lo) / U(2);
+    if (accepts(mid)) hi = mid;
+    else lo = mid;
+  }
+  return __builtin_bit_cast(T, lo);
+}
+
 template <typename T, int D>
 __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restrict__ m, const T* __restrict__ x, uint32_t nbodies,
                                                               uint32_t first, uint32_t count, uint32_t nnodes,
-                                                              tree_rec<T>* __restrict__ node, T* __restrict__ box) {
+                                                              tree_rec<T>* __restrict__ node, T* __restrict__ box, T th2) {
 #pragma clang fp contract(off)
   uint32_t li = blockIdx.x * kB + threadIdx.x;
   if (li >= count) return;
@@ -336,7 +377,9 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
     r.v[D + 1] = node_width<T, D>(b);
   }
   r.v[D + 2]                          = r.v[D + 1] * r.v[D + 1];  // the product the opening test needs, rounded once
+  r.v[D + 3]                          = open_threshold<T>(r.v[D + 2], th2);
   ba.v[D + 2] = bb.v[D + 2] = T(-1);  // a body entry is always accepted: -1 < theta^2 * d2 holds for every d2 >= 0
+  ba.v[D + 3] = bb.v[D + 3] = T(-1);  // ... and so does -1 < d2
   node[i]                             = r;
   node[uint64_t(nnodes) + 2 * li]     = ba;  // body level continues the level-order numbering: nnodes = 2^nlevels - 1
   node[uint64_t(nnodes) + 2 * li + 1] = bb;
@@ -347,7 +390,7 @@ __global__ __launch_bounds__(kB) void build_leaf_level_kernel(const T* __restric
 // by a single block looping over levels with a barrier in between.
 template <typename T, int D>
 __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_lo, tree_rec<T>* __restrict__ node,
-                                                                T* __restrict__ box) {
+                                                                T* __restrict__ box, T th2) {
 #pragma clang fp contract(off)
   for (int l = l_hi; l >= l_lo; --l) {
     // block b owns nodes [b, b + 1) * count / blocks of every level it walks: the subtree chunk under its nodes of level l_lo
@@ -383,6 +426,7 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
         r.v[D + 1] = node_width<T, D>(b);
         r.v[D + 2] = r.v[D + 1] * r.v[D + 1];
       }
+      r.v[D + 3] = open_threshold<T>(r.v[D + 2], th2);
       node[i] = r;
     }
     if (l > l_lo) {
@@ -390,6 +434,13 @@ __global__ __launch_bounds__(kB) void build_upper_levels_kernel(int l_hi, int l_
       __syncthreads();  // the next level up reads what this block wrote (nothing of any other block's)
     }
   }
+}
+
+// a traversal with another opening angle than the tree was built for: the thresholds alone are rewritten
+template <typename T, int D>
+__global__ __launch_bounds__(kB) void rethreshold_kernel(tree_rec<T>* __restrict__ node, uint32_t nnodes, T th2) {
+  const uint32_t i = blockIdx.x * kB + threadIdx.x;
+  if (i < nnodes) node[i].v[D + 3] = open_threshold<T>(node[i].v[D + 2], th2);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -934,132 +985,103 @@ __global__ __launch_bounds__(64) void bvh_force_row_kernel(const tree_rec<T>* __
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9, the sweep's step program written out as ISA (f64 described; the f32 text follows it).
+// K9, the sweep's step program written out as ISA (f64 described; the f32 text follows the same skeleton).
 //
-// The sweep above is bound by the number of instructions a step issues (vector and scalar halves barely overlap: a wave's
-// step is one dependent chain).  hipcc's schedule of the C++ step is 61 instructions; this is the same step — same tests,
-// same arithmetic in the same order, bitwise the same results and counters — written for the machine:
-//   * execution masks instead of selects: v_cmpx puts the lanes standing on the current entry in EXEC, the difference /
-//     distance / opening-test arithmetic runs for them alone, a second v_cmpx narrows EXEC to the lanes that accept, and the
-//     accepted term plus `key = skip key` run under it; the lanes that open the entry get `key + 1` under
-//     EXEC = match & ~accept.  No v_cndmask, no mask round trips, and the s_andn2 that builds the last mask is also the
-//     test for "somebody descends" (its SCC);
-//   * the position is (cur, off, span - 1): the skip key is ONE s_addc_u32 (cur + (span - 1) + "is a left child", the latter
-//     read by s_bitcmp1 from the byte offset), the child's offset one s_lshl1_add_u32;
-//   * descend and skip are two short tails instead of eight computed candidates and four selects;
-//   * a scalar compare on the record's width^2 decides whether the wave looks for near pairs at all;
-//   * the NEXT record is requested as soon as the decision is made, before the accepted term of the current one is evaluated
-//     (its mass and width^2 are copied to spare SGPRs first; VALU instructions read their scalar operands at issue, so the
-//     record registers may be overwritten by a load issued after them).
-// Measured: 23.4 VALU + 18.1 SALU + 5.5 branch + 1 SMEM instructions per step instead of 29 + 26 + 4.3 + 1; config 4 8.9 -> 7.0 ms.
-// The opening test is !(width^2 >= theta^2 d^2): for numbers the reference's `<`, for a NaN distance "accept" — a walk
-// cannot descend below the body level whatever the state holds.
+// The sweep above is bound by the number of instructions a step issues — vector AND scalar: the CU's one scalar unit serves
+// its four SIMDs in turn — so the same step (same tests in the same order per body, bitwise the same results and counters) is
+// written for the machine.  Round 4 form: 40.3 instructions per step measured at config 4 (23.0 VALU + 12.1 SALU + 4.1 branch +
+// 1.15 SMEM; round 2/3: 48.0 = 23.4 + 18.1 + 5.5 + 1; hipcc's schedule of the C++: 61):
+//   * execution masks instead of selects: v_cmpx puts the lanes standing on the current entry in EXEC, they are moved to its
+//     left child (key + 1), differences / d2 run for them alone, a second v_cmpx narrows EXEC to the lanes that accept, and
+//     `key = skip key` plus the accepted term run under it;
+//   * the opening test is ONE compare against a threshold the tree build stores in the record (open_threshold above): for every
+//     width^2 and theta^2 there is a largest v with !(w2 < fl(theta^2 * d2)) for all d2 <= v (the product is monotone in d2), so
+//     `w2 < fl(theta^2 d2)` <=> `v < d2` bit for bit.  Bodies carry v = -1 (always accepted); a NaN distance accepts, as
+//     before, so no walk can descend below the body level whatever the state holds.  The per-lane form keeps the reference's
+//     product; the tests hold the two forms equal decision by decision;
+//   * two record blocks (s[64:79], s[80:95]) and two sets of position registers used in turn by two copies of the step: the
+//     next record is requested into the other block as soon as the decision is made and the accepted term reads the mass
+//     straight from its own block (no copies), every successor is computed directly into the other set (no moves), the skip key
+//     `ka = cur + (span - 1) + "is a left child"` (one s_addc_u32) IS the other copy's `cur`;
+//   * "somebody accepted" is s_cbranch_execz on the v_cmpx result (no scalar compare), on a skip everybody did (no test);
+//     the end of the walk is tested on the skip path only (a descent cannot end it: cur + 1 < (sz << 5) - 1);
+//   * a skip requests the record of the skip key BEFORE it evaluates the current one; if some lane waits behind that key (18 %
+//     of the skips at config 4) the request is repeated for the right record once the first has landed;
+//   * a scalar compare on the threshold's high word decides whether the wave looks for near pairs at all.
+// Measured and not kept (round 4): tracking the lanes of a descent in EXEC alone (match &= ~take, no key compare and no key
+// update for the lanes that open an entry) is WRONG as it stands — lanes that came up from the subtree before wait exactly at
+// left children (the reference's parent + 1 ascent lands there) and must join the sweep when it descends to them; with those
+// waiters found by one compare after each descent it is bitwise right, one VALU instruction shorter per step and exactly as
+// fast (6.61-6.66 against 6.60-6.62 ms): what is left is not the instruction count (see DESIGN).
 // Hazards are handled by hand inside the block (gfx940 rules: a transcendental's result needs one instruction before its
-// first use, an SGPR written by a VALU instruction two before a VALU instruction reads it; SALU readers interlock).
-// The record lives in s[64:79] (fields are addressed as sub-ranges, which an asm operand cannot express).
+// first use, an SGPR written by a VALU instruction two before a VALU instruction reads it; SALU readers interlock) and
+// checked statically in the built code object (tools/check_isa_hazards.py, tools/check_smem_pipeline.py).
 // ------------------------------------------------------------------------------------------------
-#define K9_COUNT_A                                                                                                        \
-  "s_cmp_eq_u32 %[spm1], 31\n\t"                                                                                          \
-  "s_cbranch_scc1 .LK9cb%=\n\t"                                                                                           \
+#define K9_APPLY(M, ...) M(__VA_ARGS__)
+#define K9_KEEP(...) __VA_ARGS__
+#define K9_DROP(...) ""
+
+// per-body counters (tests): under EXEC = lanes on the entry.  X = "A" / "B": the copy's position registers.
+#define K9_COUNT_A(X)                                                                                                     \
+  "s_cmp_eq_u32 %[sp" X "], 31\n\t"                                                                                       \
+  "s_cbranch_scc1 .LK9cb" X "%=\n\t"                                                                                      \
   "v_add_u32_e32 %[cn], 1, %[cn]\n\t"                                                                                     \
   "s_mov_b32 %[cinc], 1\n\t"                                                                                              \
-  "s_branch .LK9cc%=\n"                                                                                                   \
-  ".LK9cb%=:\n\t"                                                                                                         \
-  "s_lshr_b32 %[t1], %[cur], 5\n\t"                                                                                       \
+  "s_branch .LK9cc" X "%=\n"                                                                                              \
+  ".LK9cb" X "%=:\n\t"                                                                                                    \
+  "s_lshr_b32 %[t1], %[cur" X "], 5\n\t"                                                                                  \
   "v_cmp_ne_u32_e32 vcc, %[t1], %[bi]\n\t"                                                                                \
   "s_not_b32 %[t2], %[t1]\n\t"                                                                                            \
   "s_and_b32 %[t2], %[t2], 1\n\t"                                                                                         \
   "v_addc_co_u32_e32 %[cb], vcc, 0, %[cb], vcc\n\t"                                                                       \
   "v_add_u32_e32 %[cl], %[t2], %[cl]\n\t"                                                                                 \
   "s_mov_b32 %[cinc], 0\n"                                                                                                \
-  ".LK9cc%=:\n\t"
+  ".LK9cc" X "%=:\n\t"
+#define K9_NOCOUNT_A(X) ""
 #define K9_COUNT_B "v_add_u32_e32 %[cm], %[cinc], %[cm]\n\t"
 
-// the accepted term's weight for r2 >= 2^-16 (pair_math<double>::weight_far, same operations in the same order); %[ms] = mass
-#define K9_FAR                                                                                                            \
+// ---- f64 pieces.  R = first SGPR of the record block as a number token pasted by the callers below.
+// the accepted term's weight for r2 >= 2^-16 (pair_math<double>::weight_far, same operations in the same order); RM = mass
+#define K9_FAR(RM)                                                                                                        \
   "v_mul_f64 %[y2], %[y], %[y]\n\t"                                                                                       \
   "v_fma_f64 %[e], -%[r2], %[y2], 1.0\n\t"                                                                                \
   "v_mul_f64 %[y], %[y], %[y2]\n\t"                                                                                       \
   "v_fma_f64 %[p], %[k1875], %[e], %[k15]\n\t"                                                                            \
   "v_ldexp_f64 %[q], -%[y], %[m52]\n\t"                                                                                   \
-  "v_mul_f64 %[y], %[y], %[ms]\n\t"                                                                                       \
+  "v_mul_f64 %[y], %[y], " RM "\n\t"                                                                                      \
   "v_fmac_f64_e32 %[q], %[p], %[e]\n\t"                                                                                   \
   "v_fmac_f64_e32 %[y], %[y], %[q]\n\t"
-
-// Z(...) keeps its argument for D = 3 and drops it for D = 2; RM / RW2 are the record's mass and width^2 register pairs,
-// RW2HI the high word of the latter.
-#define K9_ISA_TEXT(Z, RM, RW2, RW2HI, CNT_A, CNT_B)                                                                      \
-  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc0 .LK9end%=\n\t"                                                                                          \
-  "s_load_dwordx16 s[64:79], %[node], %[off]\n"                                                                           \
-  ".LK9top%=:\n\t"                                                                                                        \
-  "v_cmpx_eq_u32_e64 %[match], %[cur], %[key]\n\t"                                                                        \
-  "s_bitcmp1_b32 %[off], 6\n\t"                                                                                           \
-  "s_addc_u32 %[ka], %[cur], %[spm1]\n\t"                                                                                 \
-  CNT_A                                                                                                                   \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
-  "v_add_f64 %[d0], %[xs0], -s[64:65]\n\t"                                                                                \
-  "v_add_f64 %[d1], %[xs1], -s[66:67]\n\t"                                                                                \
-  Z("v_add_f64 %[d2], %[xs2], -s[68:69]\n\t")                                                                             \
+// differences, d2 summed as the reference does, the opening test: EXEC = lanes that accept (also in %[take])
+#define K9_TEST_F64(Z, RX, RY, RZ, RV)                                                                                    \
+  "v_add_f64 %[d0], %[xs0], -" RX "\n\t"                                                                                  \
+  "v_add_f64 %[d1], %[xs1], -" RY "\n\t"                                                                                  \
+  Z("v_add_f64 %[d2], %[xs2], -" RZ "\n\t")                                                                               \
   "v_mul_f64 %[r2], %[d0], %[d0]\n\t"                                                                                     \
   "v_mul_f64 %[t], %[d1], %[d1]\n\t"                                                                                      \
   "v_add_f64 %[r2], %[r2], %[t]\n\t"                                                                                      \
   Z("v_mul_f64 %[t], %[d2], %[d2]\n\t"                                                                                    \
     "v_add_f64 %[r2], %[r2], %[t]\n\t")                                                                                   \
-  "v_mul_f64 %[t], %[th2], %[r2]\n\t"                                                                                     \
-  "v_cmpx_nge_f64_e64 %[take], " RW2 ", %[t]\n\t"                                                                         \
-  /* the decision is made: move the lanes and the sweep, request the NEXT record, and only then evaluate this one */      \
-  "v_mov_b32_e32 %[key], %[ka]\n\t"                                                                                       \
-  "s_mov_b64 %[ms], " RM "\n\t"                                                                                           \
-  "s_mov_b32 %[w2s], " RW2HI "\n\t"                                                                                       \
-  "s_andn2_b64 exec, %[match], %[take]\n\t"                                                                               \
-  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                         \
-  "v_add_u32_e32 %[key], 1, %[key]\n\t"                                                                                   \
-  "s_add_i32 %[cur], %[cur], 1\n\t"                                                                                       \
-  "s_lshl1_add_u32 %[off], %[off], 64\n\t"                                                                                \
-  "s_lshr_b32 %[spm1], %[spm1], 1\n"                                                                                      \
-  ".LK9load%=:\n\t"                                                                                                       \
-  "s_load_dwordx16 s[64:79], %[node], %[off]\n"                                                                           \
-  ".LK9eval%=:\n\t"                                                                                                       \
-  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
-  "s_cbranch_scc0 .LK9next%=\n\t"                                                                                         \
+  "v_cmpx_nge_f64_e64 %[take], " RV ", %[r2]\n\t"
+// the accepted term under EXEC = take.  L: unique label suffix of this instance; RVHI: high word of the threshold — a body
+// record (-1) or a node so small that an accepted d2 can be below 2^-16 sends the wave to look for near pairs (K9_NEAR_F64)
+#define K9_EVAL_F64(L, Z, RM, RVHI, CNT_B)                                                                                \
   "v_rsq_f64_e32 %[y], %[r2]\n\t"                                                                                         \
   CNT_B                                                                                                                   \
-  "s_cmp_lt_i32 %[w2s], %[khi]\n\t" /* a body record (width^2 = -1) or a node so small that an accepted d2 can be < 2^-16 */\
-  "s_cbranch_scc1 .LK9maybe%=\n"                                                                                          \
-  ".LK9far%=:\n\t"                                                                                                        \
-  K9_FAR                                                                                                                  \
-  ".LK9acc%=:\n\t"                                                                                                        \
+  "s_cmp_lt_i32 " RVHI ", 0x3ef00000\n\t"                                                                                 \
+  "s_cbranch_scc1 .LK9maybe" L "%=\n"                                                                                     \
+  ".LK9far" L "%=:\n\t"                                                                                                   \
+  K9_FAR(RM)                                                                                                              \
+  ".LK9acc" L "%=:\n\t"                                                                                                   \
   "v_fma_f64 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
-  "v_fma_f64 %[acc1], -%[y], %[d1], %[acc1]\n" Z("\t" "v_fma_f64 %[acc2], -%[y], %[d2], %[acc2]\n")                       \
-  ".LK9next%=:\n\t"                                                                                                       \
-  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                          \
-  "s_branch .LK9end%=\n"                                                                                                  \
-  ".LK9skip%=:\n\t"                                                                                                       \
-  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
-  "v_cmp_gt_u32_e64 %[wt], %[ka], %[key]\n\t"                                                                             \
-  "s_lshr_b32 %[t1], %[off], 1\n\t"                                                                                       \
-  "s_add_i32 %[t2], %[off], 64\n\t"                                                                                       \
-  "s_lshl1_add_u32 %[t3], %[spm1], 1\n\t"                                                                                 \
-  "s_bitcmp1_b32 %[off], 6\n\t"                                                                                           \
-  "s_cselect_b32 %[off], %[t2], %[t1]\n\t"                                                                                \
-  "s_cselect_b32 %[spm1], %[spm1], %[t3]\n\t"                                                                             \
-  "s_mov_b32 %[cur], %[ka]\n\t"                                                                                           \
-  "s_cmp_lg_u64 %[wt], 0\n\t"                                                                                             \
-  "s_cbranch_scc1 .LK9jump%=\n"                                                                                           \
-  ".LK9chk%=:\n\t"                                                                                                        \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc1 .LK9load%=\n\t"                                                                                         \
-  "s_branch .LK9eval%=\n"                                                                                                 \
-  ".LK9maybe%=:\n\t"                                                                                                      \
+  "v_fma_f64 %[acc1], -%[y], %[d1], %[acc1]\n\t"                                                                          \
+  Z("v_fma_f64 %[acc2], -%[y], %[d2], %[acc2]\n\t")
+// out of line: some accepted entry is closer than 2^-8: those lanes take the guarded form (pair_math::weight<3>)
+#define K9_NEAR_F64(L, Z, RM)                                                                                             \
+  ".LK9maybe" L "%=:\n\t"                                                                                                 \
   "v_cmp_gt_u64_e64 %[near], %[nearhi], %[r2]\n\t"                                                                        \
   "s_cmp_eq_u64 %[near], 0\n\t"                                                                                           \
-  "s_cbranch_scc1 .LK9far%=\n\t"                                                                                          \
-  K9_FAR /* some accepted entry is closer than 2^-8: those lanes take the guarded form (pair_math::weight<3>) */          \
-  "s_mov_b64 %[wt], exec\n\t"                                                                                             \
+  "s_cbranch_scc1 .LK9far" L "%=\n\t"                                                                                     \
+  K9_FAR(RM)                                                                                                              \
   "s_mov_b64 exec, %[near]\n\t"                                                                                           \
   "v_mov_b64_e32 %[r2], %[tiny]\n\t"                                                                                      \
   "v_fmac_f64_e32 %[r2], %[d0], %[d0]\n\t"                                                                                \
@@ -1076,68 +1098,25 @@ __global__ __launch_bounds__(64) void bvh_force_row_kernel(const tree_rec<T>* __
   "v_rcp_f64_e32 %[y2], %[r2]\n\t"                                                                                        \
   "s_nop 0\n\t"                                                                                                           \
   "v_fma_f64 %[r2], -%[r2], %[y2], 1.0\n\t"                                                                               \
-  "v_mul_f64 %[y2], %[y2], %[ms]\n\t"                                                                                     \
+  "v_mul_f64 %[y2], %[y2], " RM "\n\t"                                                                                    \
   "v_fmac_f64_e32 %[r2], %[r2], %[r2]\n\t"                                                                                \
   "v_fma_f64 %[y], %[y2], %[r2], %[y2]\n\t"                                                                               \
-  "s_mov_b64 exec, %[wt]\n\t"                                                                                             \
-  "s_branch .LK9acc%=\n"                                                                                                  \
-  ".LK9jump%=:\n\t" /* lanes wait below the entry just left: continue at the smallest key any lane holds */               \
-  "s_mov_b64 vcc, %[wt]\n"                                                                                                \
-  ".LK9j1%=:\n\t"                                                                                                         \
-  "s_ff1_i32_b64 %[t1], vcc\n\t"                                                                                          \
-  "v_readlane_b32 %[cur], %[key], %[t1]\n\t"                                                                              \
-  "s_nop 1\n\t"                                                                                                           \
-  "v_cmp_gt_u32_e32 vcc, %[cur], %[key]\n\t"                                                                              \
-  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                          \
-  "s_and_b32 %[t1], %[cur], 31\n\t"                                                                                       \
-  "s_sub_i32 %[t1], %[nlev], %[t1]\n\t"                                                                                   \
-  "s_lshl_b32 %[t2], -1, %[cur]\n\t"                                                                                      \
-  "s_not_b32 %[t2], %[t2]\n\t"                                                                                            \
-  "s_lshr_b32 %[t3], %[cur], 5\n\t"                                                                                       \
-  "s_lshr_b32 %[t3], %[t3], %[t1]\n\t"                                                                                    \
-  "s_add_i32 %[t3], %[t3], %[t2]\n\t"                                                                                     \
-  "s_lshl_b32 %[off], %[t3], 6\n\t"                                                                                       \
-  "s_lshl_b32 %[spm1], 32, %[t1]\n\t"                                                                                     \
-  "s_add_i32 %[spm1], %[spm1], -1\n\t"                                                                                    \
-  "s_branch .LK9chk%=\n"                                                                                                  \
-  ".LK9end%=:\n\t"                                                                                                        \
-  "s_mov_b64 exec, %[sv]"
-// The same step program for single precision: 32-byte records in s[64:71] (off counts 32-byte units), the opening test on the
-// unfused d2 as in dist2_ref, the accepted term as pair_math<float>::weight on the fused r2 (no near path: 1-ulp seeds).
-#define K9_ISA_TEXT_F32(Z, RM, RW2, CNT_A, CNT_B)                                                                         \
-  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc0 .LK9end%=\n\t"                                                                                          \
-  "s_load_dwordx8 s[64:71], %[node], %[off]\n"                                                                            \
-  ".LK9top%=:\n\t"                                                                                                        \
-  "v_cmpx_eq_u32_e64 %[match], %[cur], %[key]\n\t"                                                                        \
-  "s_bitcmp1_b32 %[off], 5\n\t"                                                                                           \
-  "s_addc_u32 %[ka], %[cur], %[spm1]\n\t"                                                                                 \
-  CNT_A                                                                                                                   \
-  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
-  "v_subrev_f32_e32 %[d0], s64, %[xs0]\n\t"                                                                               \
-  "v_subrev_f32_e32 %[d1], s65, %[xs1]\n\t"                                                                               \
-  Z("v_subrev_f32_e32 %[d2], s66, %[xs2]\n\t")                                                                            \
+  "s_mov_b64 exec, %[take]\n\t"                                                                                           \
+  "s_branch .LK9acc" L "%=\n"
+
+// ---- f32 pieces: 32-byte records, the opening test on the unfused d2 as in dist2_ref, the accepted term as
+// pair_math<float>::weight on the fused r2 (no near path: 1-ulp seeds)
+#define K9_TEST_F32(Z, RX, RY, RZ, RV)                                                                                    \
+  "v_subrev_f32_e32 %[d0], " RX ", %[xs0]\n\t"                                                                            \
+  "v_subrev_f32_e32 %[d1], " RY ", %[xs1]\n\t"                                                                            \
+  Z("v_subrev_f32_e32 %[d2], " RZ ", %[xs2]\n\t")                                                                         \
   "v_mul_f32_e32 %[r2], %[d0], %[d0]\n\t"                                                                                 \
   "v_mul_f32_e32 %[t], %[d1], %[d1]\n\t"                                                                                  \
   "v_add_f32_e32 %[r2], %[r2], %[t]\n\t"                                                                                  \
   Z("v_mul_f32_e32 %[t], %[d2], %[d2]\n\t"                                                                                \
     "v_add_f32_e32 %[r2], %[r2], %[t]\n\t")                                                                               \
-  "v_mul_f32_e32 %[t], %[th2], %[r2]\n\t"                                                                                 \
-  "v_cmpx_nge_f32_e64 %[take], " RW2 ", %[t]\n\t"                                                                         \
-  "v_mov_b32_e32 %[key], %[ka]\n\t"                                                                                       \
-  "s_mov_b32 %[ms], " RM "\n\t"                                                                                           \
-  "s_andn2_b64 exec, %[match], %[take]\n\t"                                                                               \
-  "s_cbranch_scc0 .LK9skip%=\n\t"                                                                                         \
-  "v_add_u32_e32 %[key], 1, %[key]\n\t"                                                                                   \
-  "s_add_i32 %[cur], %[cur], 1\n\t"                                                                                       \
-  "s_lshl1_add_u32 %[off], %[off], 32\n\t"                                                                                \
-  "s_lshr_b32 %[spm1], %[spm1], 1\n"                                                                                      \
-  ".LK9load%=:\n\t"                                                                                                       \
-  "s_load_dwordx8 s[64:71], %[node], %[off]\n"                                                                            \
-  ".LK9eval%=:\n\t"                                                                                                       \
-  "s_and_b64 exec, %[take], %[take]\n\t"                                                                                  \
-  "s_cbranch_scc0 .LK9next%=\n\t"                                                                                         \
+  "v_cmpx_nge_f32_e64 %[take], " RV ", %[r2]\n\t"
+#define K9_EVAL_F32(L, Z, RM, RVHI, CNT_B)                                                                                \
   "v_fma_f32 %[r2], %[d0], %[d0], %[tiny]\n\t"                                                                            \
   "v_fmac_f32_e32 %[r2], %[d1], %[d1]\n\t"                                                                                \
   Z("v_fmac_f32_e32 %[r2], %[d2], %[d2]\n\t")                                                                             \
@@ -1148,62 +1127,115 @@ __global__ __launch_bounds__(64) void bvh_force_row_kernel(const tree_rec<T>* __
   "v_fma_f32 %[y], %[r2], %[y], %[eps]\n\t"                                                                               \
   "v_rcp_f32_e32 %[y], %[y]\n\t"                                                                                          \
   "s_nop 0\n\t"                                                                                                           \
-  "v_mul_f32_e32 %[y], %[ms], %[y]\n\t"                                                                                   \
+  "v_mul_f32_e32 %[y], " RM ", %[y]\n\t"                                                                                  \
   "v_fma_f32 %[acc0], -%[y], %[d0], %[acc0]\n\t"                                                                          \
-  "v_fma_f32 %[acc1], -%[y], %[d1], %[acc1]\n" Z("\t" "v_fma_f32 %[acc2], -%[y], %[d2], %[acc2]\n")                       \
-  ".LK9next%=:\n\t"                                                                                                       \
+  "v_fma_f32 %[acc1], -%[y], %[d1], %[acc1]\n\t"                                                                          \
+  Z("v_fma_f32 %[acc2], -%[y], %[d2], %[acc2]\n\t")
+#define K9_NEAR_F32(L, Z, RM) ""
+
+// ---- the skeleton.  One copy of the step: X = this copy ("A" / "B"), Y = the other; BIT / RBS = log2 / value of the record
+// size; LOADY requests the record at off<Y> into Y's block; TEST / EVALD / EVALS are the pieces above with X's registers
+// (two EVAL instances per copy: labels must differ); TAIL closes the main line of the copy.
+#define K9_STEP(X, Y, BIT, RBS, LOADY, CNT_A, TEST, EVALD, TAIL)                                                          \
+  ".LK9top" X "%=:\n\t"                                                                                                   \
+  "v_cmpx_eq_u32_e64 %[match], %[cur" X "], %[key]\n\t" /* EXEC = the lanes standing on the entry */                      \
+  "s_bitcmp1_b32 %[off" X "], " BIT "\n\t"                                                                                \
+  "s_addc_u32 %[cur" Y "], %[cur" X "], %[sp" X "]\n\t" /* the skip key: cur + (span - 1) + (left child) */               \
+  CNT_A(X)                                                                                                                \
+  "v_add_u32_e32 %[key], 1, %[key]\n\t"        /* they move to its left child ... */                                      \
+  "s_waitcnt lgkmcnt(0)\n\t"                                                                                              \
+  TEST                                                                                                                    \
+  "v_mov_b32_e32 %[key], %[cur" Y "]\n\t"      /* ... except those that accept it: the skip key */                        \
+  "s_andn2_b64 %[op], %[match], %[take]\n\t"   /* SCC: somebody opens the entry */                                        \
+  "s_cbranch_scc0 .LK9skip" X "%=\n\t"                                                                                    \
+  "s_add_i32 %[cur" Y "], %[cur" X "], 1\n\t"                                                                             \
+  "s_lshl1_add_u32 %[off" Y "], %[off" X "], " RBS "\n\t"                                                                 \
+  "s_lshr_b32 %[sp" Y "], %[sp" X "], 1\n\t"                                                                              \
+  LOADY                                                                                                                   \
+  "s_cbranch_execz .LK9dn" X "%=\n\t"        /* nobody accepted */                                                        \
+  EVALD                                                                                                                   \
+  ".LK9dn" X "%=:\n\t"                                                                                                    \
   "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc1 .LK9top%=\n\t"                                                                                          \
+  TAIL
+// out of line: nobody opens the entry (every lane on it accepted; EXEC = those lanes, cur<Y> = their skip key)
+#define K9_SKIP(X, Y, BIT, RBS, RBSH, LOADY, EVALS)                                                                       \
+  ".LK9skip" X "%=:\n\t"                                                                                                  \
+  "s_lshr_b32 %[t1], %[off" X "], 1\n\t"        /* right child -> parent + 1 */                                           \
+  "s_add_i32 %[t2], %[off" X "], " RBS "\n\t"   /* left child -> sibling */                                               \
+  "s_lshl1_add_u32 %[t3], %[sp" X "], 1\n\t"                                                                              \
+  "s_bitcmp1_b32 %[off" X "], " BIT "\n\t"                                                                                \
+  "s_cselect_b32 %[off" Y "], %[t2], %[t1]\n\t"                                                                           \
+  "s_cselect_b32 %[sp" Y "], %[sp" X "], %[t3]\n\t"                                                                       \
+  LOADY                                                                                                                   \
+  EVALS                                                                                                                   \
+  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
+  "v_cmp_gt_u32_e32 vcc, %[cur" Y "], %[key]\n\t"          /* lanes waiting below the entry just left */                  \
+  "s_cbranch_vccnz .LK9jump" X "%=\n\t"                                                                                   \
+  "s_cmp_lt_u32 %[cur" Y "], %[endk]\n\t"                                                                                 \
+  "s_cbranch_scc1 .LK9top" Y "%=\n\t"                                                                                     \
   "s_branch .LK9end%=\n"                                                                                                  \
-  ".LK9skip%=:\n\t"                                                                                                       \
-  "s_mov_b64 exec, %[sv]\n\t"                                                                                             \
-  "v_cmp_gt_u32_e64 %[wt], %[ka], %[key]\n\t"                                                                             \
-  "s_lshr_b32 %[t1], %[off], 1\n\t"                                                                                       \
-  "s_add_i32 %[t2], %[off], 32\n\t"                                                                                       \
-  "s_lshl1_add_u32 %[t3], %[spm1], 1\n\t"                                                                                 \
-  "s_bitcmp1_b32 %[off], 5\n\t"                                                                                           \
-  "s_cselect_b32 %[off], %[t2], %[t1]\n\t"                                                                                \
-  "s_cselect_b32 %[spm1], %[spm1], %[t3]\n\t"                                                                             \
-  "s_mov_b32 %[cur], %[ka]\n\t"                                                                                           \
-  "s_cmp_lg_u64 %[wt], 0\n\t"                                                                                             \
-  "s_cbranch_scc1 .LK9jump%=\n"                                                                                           \
-  ".LK9chk%=:\n\t"                                                                                                        \
-  "s_cmp_lt_u32 %[cur], %[endk]\n\t"                                                                                      \
-  "s_cbranch_scc1 .LK9load%=\n\t"                                                                                         \
-  "s_branch .LK9eval%=\n"                                                                                                 \
-  ".LK9jump%=:\n\t"                                                                                                       \
-  "s_mov_b64 vcc, %[wt]\n"                                                                                                \
-  ".LK9j1%=:\n\t"                                                                                                         \
+  ".LK9jump" X "%=:\n\t" /* continue at the smallest key any lane holds; the record requested above is not the one */     \
   "s_ff1_i32_b64 %[t1], vcc\n\t"                                                                                          \
-  "v_readlane_b32 %[cur], %[key], %[t1]\n\t"                                                                              \
+  "v_readlane_b32 %[cur" Y "], %[key], %[t1]\n\t"                                                                         \
   "s_nop 1\n\t"                                                                                                           \
-  "v_cmp_gt_u32_e32 vcc, %[cur], %[key]\n\t"                                                                              \
-  "s_cbranch_vccnz .LK9j1%=\n\t"                                                                                          \
-  "s_and_b32 %[t1], %[cur], 31\n\t"                                                                                       \
+  "v_cmp_gt_u32_e32 vcc, %[cur" Y "], %[key]\n\t"                                                                         \
+  "s_cbranch_vccnz .LK9jump" X "%=\n\t"                                                                                   \
+  "s_cmp_lt_u32 %[cur" Y "], %[endk]\n\t" /* only finished lanes were behind: their keys are positions past the tree */   \
+  "s_cbranch_scc0 .LK9end%=\n\t"                                                                                          \
+  "s_and_b32 %[t1], %[cur" Y "], 31\n\t"                                                                                  \
   "s_sub_i32 %[t1], %[nlev], %[t1]\n\t"                                                                                   \
-  "s_lshl_b32 %[t2], -1, %[cur]\n\t"                                                                                      \
+  "s_lshl_b32 %[t2], -1, %[cur" Y "]\n\t"                                                                                 \
   "s_not_b32 %[t2], %[t2]\n\t"                                                                                            \
-  "s_lshr_b32 %[t3], %[cur], 5\n\t"                                                                                       \
+  "s_lshr_b32 %[t3], %[cur" Y "], 5\n\t"                                                                                  \
   "s_lshr_b32 %[t3], %[t3], %[t1]\n\t"                                                                                    \
   "s_add_i32 %[t3], %[t3], %[t2]\n\t"                                                                                     \
-  "s_lshl_b32 %[off], %[t3], 5\n\t"                                                                                       \
-  "s_lshl_b32 %[spm1], 32, %[t1]\n\t"                                                                                     \
-  "s_add_i32 %[spm1], %[spm1], -1\n\t"                                                                                    \
-  "s_branch .LK9chk%=\n"                                                                                                  \
+  "s_lshl_b32 %[off" Y "], %[t3], " RBSH "\n\t"                                                                           \
+  "s_lshl_b32 %[sp" Y "], 32, %[t1]\n\t"                                                                                  \
+  "s_add_i32 %[sp" Y "], %[sp" Y "], -1\n\t"                                                                              \
+  "s_waitcnt lgkmcnt(0)\n\t" /* the first request must have landed before its registers are requested again */            \
+  LOADY                                                                                                                   \
+  "s_branch .LK9top" Y "%=\n"
+
+#define K9_LOAD16(BLK, O) "s_load_dwordx16 " BLK ", %[node], %[off" O "]\n\t"
+#define K9_LOAD8(BLK, O) "s_load_dwordx8 " BLK ", %[node], %[off" O "]\n\t"
+
+// f64: A = s[64:79], B = s[80:95].  D = 3: x s[0:1] y s[2:3] z s[4:5] m s[6:7] w s[8:9] w2 s[10:11] v s[12:13] of the block;
+// D = 2: x s[0:1] y s[2:3] m s[4:5] w s[6:7] w2 s[8:9] v s[10:11].
+#define K9_PROGRAM_F64(Z, AX, AY, AZ, AM, AV, AVHI, BX, BY, BZ, BM, BV, BVHI, CNT_A, CNT_B)                               \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  K9_LOAD16("s[64:79]", "A")                                                                                              \
+  K9_STEP("A", "B", "6", "64", K9_LOAD16("s[80:95]", "B"), CNT_A, K9_TEST_F64(Z, AX, AY, AZ, AV),                         \
+          K9_EVAL_F64("Ad", Z, AM, AVHI, CNT_B), "")                                                                    \
+  K9_STEP("B", "A", "6", "64", K9_LOAD16("s[64:79]", "A"), CNT_A, K9_TEST_F64(Z, BX, BY, BZ, BV),                         \
+          K9_EVAL_F64("Bd", Z, BM, BVHI, CNT_B), "s_branch .LK9topA%=\n")                                               \
+  K9_SKIP("A", "B", "6", "64", "6", K9_LOAD16("s[80:95]", "B"), K9_EVAL_F64("As", Z, AM, AVHI, CNT_B))                    \
+  K9_SKIP("B", "A", "6", "64", "6", K9_LOAD16("s[64:79]", "A"), K9_EVAL_F64("Bs", Z, BM, BVHI, CNT_B))                    \
+  K9_NEAR_F64("Ad", Z, AM) K9_NEAR_F64("As", Z, AM) K9_NEAR_F64("Bd", Z, BM) K9_NEAR_F64("Bs", Z, BM)                     \
   ".LK9end%=:\n\t"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t" /* a record requested past the end of the walk: it must land before the registers are reused */ \
   "s_mov_b64 exec, %[sv]"
-#define K9_KEEP(...) __VA_ARGS__
-#define K9_DROP(...) ""
+// f32: A = s[64:71], B = s[80:87].  D = 3: x y z m w w2 v = s0..s6 of the block; D = 2: x y m w w2 v = s0..s5.
+#define K9_PROGRAM_F32(Z, AX, AY, AZ, AM, AV, BX, BY, BZ, BM, BV, CNT_A, CNT_B)                                           \
+  "s_mov_b64 %[sv], exec\n\t"                                                                                             \
+  K9_LOAD8("s[64:71]", "A")                                                                                               \
+  K9_STEP("A", "B", "5", "32", K9_LOAD8("s[80:87]", "B"), CNT_A, K9_TEST_F32(Z, AX, AY, AZ, AV),                          \
+          K9_EVAL_F32("Ad", Z, AM, "", CNT_B), "")                                                                      \
+  K9_STEP("B", "A", "5", "32", K9_LOAD8("s[64:71]", "A"), CNT_A, K9_TEST_F32(Z, BX, BY, BZ, BV),                          \
+          K9_EVAL_F32("Bd", Z, BM, "", CNT_B), "s_branch .LK9topA%=\n")                                                 \
+  K9_SKIP("A", "B", "5", "32", "5", K9_LOAD8("s[80:87]", "B"), K9_EVAL_F32("As", Z, AM, "", CNT_B))                       \
+  K9_SKIP("B", "A", "5", "32", "5", K9_LOAD8("s[64:71]", "A"), K9_EVAL_F32("Bs", Z, BM, "", CNT_B))                       \
+  ".LK9end%=:\n\t"                                                                                                        \
+  "s_waitcnt lgkmcnt(0)\n\t" /* a record requested past the end of the walk: it must land before the registers are reused */ \
+  "s_mov_b64 exec, %[sv]"
 
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
                                                                  const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
-                                                                 uint32_t count, T theta2, uint32_t nlevels,
+                                                                 uint32_t count, uint32_t nlevels,
                                                                  uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
                                                                  const uint32_t* __restrict__ nitems, uint32_t stride, uint32_t parts) {
   static_assert(sizeof(tree_rec<T>) == 8 * sizeof(T), "the step program addresses records of 8 scalars");
-  // work item of this block, as in bvh_force_wave_kernel
+  // work item of this block: with an item list, the XCD it runs on (block index mod 8) owns one list (bvh_items_kernel)
   uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
   if (items) {
     const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
@@ -1220,67 +1252,79 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   const uint32_t local = group * 64u + threadIdx.x;
   const bool valid     = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
   const uint32_t bi    = first + (valid ? local : 0u);
+  // A lane's key is the packed position (covered << 5 | level) of the entry it visits next; it keeps counting past the end
+  // (covered >= sz: finished), so only lanes outside the item need a sentinel.
   uint32_t key         = valid ? 0u : 0xffffffffu;
   T xs[3] = {T(0), T(0), T(0)}, acc[3] = {T(0), T(0), T(0)};
 #pragma unroll
   for (int k = 0; k < D; ++k) xs[k] = x[uint64_t(bi) * D + k];
   uint32_t cn = 0, cl = 0, cm = 0, cb = 0;
-  uint32_t cur = 0, off = 0, spm1 = (32u << nlevels) - 1u;
-  const uint32_t endk = (sz << 5) - 1u;  // see bvh_force_wave_kernel
-  uint32_t ka, t1, t2, t3, cinc;
-  uint64_t match, take, wt, sv;
-#define K9_CLOBBER8 "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+  // the sweep's position: packed key, byte offset of the record (level-order index * record size), (32 << levels below) - 1
+  uint32_t curA = 0, offA = 0, spA = (32u << nlevels) - 1u, curB, offB, spB;
+  // cur >= (sz << 5) - 1: every remaining key is >= cur and covered >= sz: all lanes are finished.  One less than sz << 5 because
+  // an accepted ROOT is left by the ascend rule with covered + 2^nlevels and level - 1 = 31 after the borrow, which is
+  // (sz << 5) - 1 when sz is a power of two; no live key has level 31.
+  const uint32_t endk = (sz << 5) - 1u;
+  uint32_t t1, t2, t3, cinc;
+  uint64_t match, take, op, sv;
+#define K9_CLOBBER8                                                                                                        \
+  "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87"
   if constexpr (sizeof(T) == 8) {
     const pair_consts<double> pc;
     double k0375 = 0.375, tiny = pair_math<double>::tiny, eps = DBL_EPSILON;
     uint64_t nearhi = uint64_t(pair_math<double>::near_hi) << 32;
     int m52 = -52;
-    // An accepted entry satisfies width^2 < fl(theta^2 d2); with d2 < 2^-16 that is <= theta^2 * 2^-16 (exact scaling), so only
-    // records whose width^2 has a high word <= that bound's — and body records, width^2 = -1, negative as an integer — can hold
-    // a near pair: a scalar compare decides whether the wave looks at all.
-    int khi = to_sgpr(int(uint32_t(__builtin_bit_cast(unsigned long long, theta2 * 0x1p-16) >> 32)) + 1);  // (a VALU product)
     asm volatile("" : "+s"(k0375), "+s"(nearhi), "+s"(m52), "+v"(tiny), "+v"(eps));
-    double d0, d1, d2, r2, t, y, y2, e, p, q, ms;
-    uint32_t w2s;
+    double d0, d1, d2, r2, t, y, y2, e, p, q;
     uint64_t near;
 #define K9_OPERANDS                                                                                                        \
-  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
-    [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
-    [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q),    \
-    [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take),              \
-    [near] "=&s"(near), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms), [w2s] "=&s"(w2s), [cinc] "=&s"(cinc)               \
-  : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi), \
-    [k0375] "s"(k0375), [m52] "s"(m52), [khi] "s"(khi), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]),              \
-    [k15] "v"(pc.k15), [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                      \
-  : K9_CLOBBER8, "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [curA] "+s"(curA), [offA] "+s"(offA),    \
+    [spA] "+s"(spA), [curB] "=&s"(curB), [offB] "=&s"(offB), [spB] "=&s"(spB), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm),  \
+    [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y),              \
+    [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3),               \
+    [match] "=&s"(match), [take] "=&s"(take), [op] "=&s"(op), [near] "=&s"(near), [sv] "=&s"(sv), [cinc] "=&s"(cinc)                       \
+  : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi),                  \
+    [k0375] "s"(k0375), [m52] "s"(m52), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
+    [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
+  : K9_CLOBBER8, "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
+#define K9_REGS3                                                                                                           \
+  "s[64:65]", "s[66:67]", "s[68:69]", "s[70:71]", "s[76:77]", "s77", "s[80:81]", "s[82:83]", "s[84:85]", "s[86:87]", "s[92:93]", "s93"
+#define K9_REGS2                                                                                                           \
+  "s[64:65]", "s[66:67]", "", "s[68:69]", "s[74:75]", "s75", "s[80:81]", "s[82:83]", "", "s[84:85]", "s[90:91]", "s91"
     if constexpr (D == 3) {
-      if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-      else asm volatile(K9_ISA_TEXT(K9_KEEP, "s[70:71]", "s[74:75]", "s75", "", "") K9_OPERANDS);
+      if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_NOCOUNT_A, "") K9_OPERANDS);
     } else {
-      if constexpr (COUNT) asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-      else asm volatile(K9_ISA_TEXT(K9_DROP, "s[68:69]", "s[72:73]", "s73", "", "") K9_OPERANDS);
+      if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_DROP, K9_REGS2, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_DROP, K9_REGS2, K9_NOCOUNT_A, "") K9_OPERANDS);
     }
+#undef K9_REGS3
+#undef K9_REGS2
 #undef K9_OPERANDS
   } else {
     float tiny = pair_math<float>::tiny, eps = FLT_EPSILON;
     asm volatile("" : "+s"(tiny), "+s"(eps));
-    float d0, d1, d2, r2, t, y, ms;
+    float d0, d1, d2, r2, t, y;
 #define K9_OPERANDS                                                                                                        \
-  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [cur] "+s"(cur), [off] "+s"(off),        \
-    [spm1] "+s"(spm1), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm), [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1),          \
-    [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y), [ka] "=&s"(ka), [t1] "=&s"(t1), [t2] "=&s"(t2),            \
-    [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take), [wt] "=&s"(wt), [sv] "=&s"(sv), [ms] "=&s"(ms),              \
-    [cinc] "=&s"(cinc)                                                                                                     \
-  : [node] "s"(node), [th2] "s"(theta2), [nlev] "s"(nlevels), [endk] "s"(endk), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]),        \
-    [xs2] "v"(xs[2]), [tiny] "s"(tiny), [eps] "s"(eps), [bi] "v"(bi)                                                       \
+  : [acc0] "+v"(acc[0]), [acc1] "+v"(acc[1]), [acc2] "+v"(acc[2]), [key] "+v"(key), [curA] "+s"(curA), [offA] "+s"(offA),    \
+    [spA] "+s"(spA), [curB] "=&s"(curB), [offB] "=&s"(offB), [spB] "=&s"(spB), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm),  \
+    [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y),              \
+    [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take), [op] "=&s"(op),              \
+    [sv] "=&s"(sv), [cinc] "=&s"(cinc)                                                                                                     \
+  : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]),         \
+    [tiny] "s"(tiny), [eps] "s"(eps), [bi] "v"(bi)                                                                         \
   : K9_CLOBBER8
+#define K9_REGS3 "s64", "s65", "s66", "s67", "s70", "s80", "s81", "s82", "s83", "s86"
+#define K9_REGS2 "s64", "s65", "", "s66", "s69", "s80", "s81", "", "s82", "s85"
     if constexpr (D == 3) {
-      if constexpr (COUNT) asm volatile(K9_ISA_TEXT_F32(K9_KEEP, "s67", "s69", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-      else asm volatile(K9_ISA_TEXT_F32(K9_KEEP, "s67", "s69", "", "") K9_OPERANDS);
+      if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_KEEP, K9_REGS3, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_KEEP, K9_REGS3, K9_NOCOUNT_A, "") K9_OPERANDS);
     } else {
-      if constexpr (COUNT) asm volatile(K9_ISA_TEXT_F32(K9_DROP, "s66", "s68", K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
-      else asm volatile(K9_ISA_TEXT_F32(K9_DROP, "s66", "s68", "", "") K9_OPERANDS);
+      if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_DROP, K9_REGS2, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
+      else asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_DROP, K9_REGS2, K9_NOCOUNT_A, "") K9_OPERANDS);
     }
+#undef K9_REGS3
+#undef K9_REGS2
 #undef K9_OPERANDS
   }
 #undef K9_CLOBBER8
@@ -1360,8 +1404,10 @@ static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   T* box             = static_cast<T*>(t->box);
   const int last     = int(t->nlevels) - 1;
   const uint32_t cnt = 1u << last;
+  const T th         = static_cast<T>(t->theta);
+  const T th2        = th * th;  // src/bvh.h:252, in T: the opening thresholds of the records are written for it
   hipLaunchKernelGGL((build_leaf_level_kernel<T, D>), dim3((cnt + kB - 1) / kB), dim3(kB), 0, st, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, t->nnodes, node, box);
+                     static_cast<const T*>(s->x), s->sz, cnt - 1u, cnt, t->nnodes, node, box, th2);
   NB_HIP(hipGetLastError());
   // Nine levels per launch: a block takes 256 nodes of the deepest one and follows their subtree chunk up to its single node nine
   // levels higher, with block barriers between the levels (one launch per level was 8 dependent launches at N = 10^5, 11 at 10^6);
@@ -1369,15 +1415,16 @@ static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
   for (int l = last - 1; l >= 0;) {
     if ((1u << l) > uint32_t(kB)) {
       const int lo = l - 8 > 0 ? l - 8 : 0;
-      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3((1u << l) / kB), dim3(kB), 0, st, l, lo, node, box);
+      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3((1u << l) / kB), dim3(kB), 0, st, l, lo, node, box, th2);
       NB_HIP(hipGetLastError());
       l = lo - 1;
     } else {
-      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3(1), dim3(kB), 0, st, l, 0, node, box);
+      hipLaunchKernelGGL((build_upper_levels_kernel<T, D>), dim3(1), dim3(kB), 0, st, l, 0, node, box, th2);
       NB_HIP(hipGetLastError());
       l = -1;
     }
   }
+  t->th2_built = double(th2);
   return NBODY_OK;
 }
 
@@ -1387,6 +1434,13 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th  = static_cast<T>(theta);
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
+  t->theta   = theta;  // the next build writes the records' opening thresholds for this angle
+  if (t->th2_built != double(th2)) {
+    hipLaunchKernelGGL((rethreshold_kernel<T, D>), dim3((t->nnodes + kB - 1) / kB), dim3(kB), 0, st,
+                       static_cast<tree_rec<T>*>(t->node), t->nnodes, th2);
+    NB_HIP(hipGetLastError());
+    t->th2_built = double(th2);
+  }
   // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
   // 256 CUs (ms per whole bvh step over the first 200 steps of the galaxy, sweep / per-lane): f64 (hand-scheduled sweep) 0.90 / 0.85
   // at 4*10^4, 1.0 / 1.0 at 6*10^4, 1.1 / 1.15 at 8*10^4, 1.2 / 1.25 at 10^5, 1.3 / 1.5 at 1.3*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1
@@ -1469,8 +1523,12 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
   } else if (wave && isa) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, true>), NB_WARGS);
-    else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_WARGS);
+#define NB_IARGS                                                                                                             \
+  dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
+   s->first, s->count, t->nlevels, t->counters, items, nitems, stride, parts
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, true>), NB_IARGS);
+    else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_IARGS);
+#undef NB_IARGS
   } else if (wave) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
@@ -1660,6 +1718,19 @@ extern "C" int nbody_bvh_compute_force(nbody_bvh* t, const nbody_state* s, doubl
   });
 }
 
+extern "C" int nbody_bvh_opening_thresholds(int dtype, const void* width2, double theta, size_t n, void* out) {
+  NB_ARG(dtype == NBODY_F32 || dtype == NBODY_F64, "bad dtype %d", dtype);
+  NB_ARG((width2 != nullptr && out != nullptr) || n == 0, "NULL argument");
+  if (dtype == NBODY_F32) {
+    const float th = static_cast<float>(theta), th2 = th * th;
+    for (size_t i = 0; i < n; ++i) static_cast<float*>(out)[i] = open_threshold<float>(static_cast<const float*>(width2)[i], th2);
+  } else {
+    const double th2 = theta * theta;
+    for (size_t i = 0; i < n; ++i) static_cast<double*>(out)[i] = open_threshold<double>(static_cast<const double*>(width2)[i], th2);
+  }
+  return NBODY_OK;
+}
+
 extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream) {
   NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
   device_guard guard(t->device);
@@ -1674,9 +1745,15 @@ extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t byt
   switch (what) {
     case 0: return copy_out(t->keys[0], sizeof(uint64_t) * size_t(t->n));
     case 1: return copy_out(t->idx[t->final_buf], sizeof(uint32_t) * size_t(t->n));
+    case 6:
+      if (t->th2_built < 0.0) {
+        set_error("nbody_bvh_read(what=6) before nbody_bvh_build_tree");
+        return NBODY_ERR_STATE;
+      }
+      [[fallthrough]];
     case 3:
     case 2: {
-      // unpack node records -> T[nnodes][D+1] (what=2) or T[nnodes] (what=3)
+      // unpack node records -> T[nnodes][D+1] (what=2), T[nnodes] widths (what=3) or opening thresholds (what=6)
       const size_t need = what == 2 ? t->tsz * (D + 1) * t->nnodes : t->tsz * t->nnodes;
       NB_ARG(bytes == need, "nbody_bvh_read(what=%d): expected %zu bytes, got %zu", what, need, bytes);
       char* raw = static_cast<char*>(malloc(t->rec_bytes * size_t(t->nnodes)));
@@ -1691,7 +1768,7 @@ extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t byt
       for (size_t i = 0; i < t->nnodes; ++i) {
         const char* r = raw + i * t->rec_bytes;
         if (what == 2) memcpy(o + i * t->tsz * (D + 1), r, t->tsz * (D + 1));
-        else memcpy(o + i * t->tsz, r + t->tsz * (D + 1), t->tsz);
+        else memcpy(o + i * t->tsz, r + t->tsz * (D + (what == 3 ? 1 : 3)), t->tsz);
       }
       free(raw);
       return NBODY_OK;

@@ -3,12 +3,15 @@ import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
 from conftest import load_package
 nb = load_package()
+if "exp" in sys.argv[1:]:   # the -DNBODY_EXPERIMENTS build as it lies in the tree (built with whatever EXPDEFS the caller chose)
+    nb.LIB_PATH = os.path.join(os.path.dirname(nb.LIB_PATH), "libnbody_hip_exp.so")
+    print("library:", nb.LIB_PATH)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64
 dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
 st, t = dev.state(), dev.bvh
 t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream); dev.sync()
-for mode in (1, 3, 5, 6):
+for mode in (1, 3, 5):
     t.set_traversal(mode)
     t.compute_force(st, 0.5, dev.stream); dev.sync()
     acc = dev.download().a.copy()

@@ -461,7 +461,7 @@ def main():
         if fault == "corrupt_a":
             sim.a[sim.count // 2] += 1e-9
         scratch = torch.empty((WIN, 3), dtype=sim.a.dtype, device=dev)
-        checked, mismatch = [], []
+        checked, mismatch, k1_failed, window_desc = [], [], "", None
         for p, (pf, pe) in enumerate(sim.shards):
             cnt = min(WIN, pe - pf)
             off = (pe - pf - cnt) // 2
@@ -473,19 +473,24 @@ def main():
                 st = sim.state()
                 st.first, st.count = pf + off, cnt
                 st.a = st.v = st.ao = scratch.data_ptr()   # K1 writes a only; v/ao are not touched by it
+                window_desc = nb.describe_all_pairs(st)  # a short window: one chunk per block, whatever shape the ranks' launches had
                 rc = nb.lib().nbody_all_pairs_force(C.byref(st), C.c_void_p(sim._stream()))
-                if rc:
-                    fail_all("bitwise_vs_single: K1 on the window failed: " + nb.lib().nbody_last_error().decode())
+                if rc:  # no exit here: the other ranks wait in the broadcast below; the verdict carries the failure to all of them
+                    k1_failed = k1_failed or nb.lib().nbody_last_error().decode()
+                    continue
                 torch.cuda.synchronize()
                 checked.append(p)
                 if not torch.equal(scratch[:cnt].to(red_dev), rows[:cnt]):
                     mismatch.append(p)
-        verdict = torch.tensor([len(mismatch)], dtype=torch.int32, device=red_dev)
+        verdict = torch.tensor([-1 if k1_failed else len(mismatch)], dtype=torch.int32, device=red_dev)
         dist.broadcast(verdict, src=0)
+        if int(verdict.item()) < 0:
+            fail_all("bitwise_vs_single: rank 0's K1 on a window failed" + (": " + k1_failed if rank == 0 else " (reason on rank 0)"))
         if int(verdict.item()) != 0:
             fail_all("bitwise_vs_single failed: rank 0's K1 on a %d-target window of rank(s) %s differs from the rows those ranks "
                      "computed (stale positions on a rank, or a window-dependent sum): the run is void" % (WIN, mismatch if rank == 0 else "?"))
         bitwise = {"equal": True, "checked_ranks": checked, "targets_per_window": WIN,
+                   "launch_shapes": {"rank_shard": kernel_desc, "window": window_desc},
                    "how": "after the timed steps every rank recomputed K1 on its shard; rank 0 recomputed a window in the middle of "
                           "each rank's shard from its own x and compared the rows bit for bit"}
 

@@ -635,7 +635,7 @@ inline int check_tuning(int split, int tpt, int path) {
 }
 
 // all_pairs.hip: per-(device, stream) packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
-int ap_scratch_reserve(hipStream_t st, int dtype, int dim, uint32_t n);
+int ap_scratch_reserve(hipStream_t st, const nbody_state* view);
 void ap_scratch_release(hipStream_t st);
 int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 chunk sums, 2 energies, 3 bounding-box keys
 int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);

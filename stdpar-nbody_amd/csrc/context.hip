@@ -85,7 +85,9 @@ extern "C" int nbody_create(nbody_ctx** out, int dtype, int dim, uint32_t n, int
     nbody_destroy(c);
     return r;
   }
-  if (int r = ap_scratch_reserve(c->stream, dtype, dim, n)) {  // so that a recorded step never allocates
+  nbody_state view;
+  (void)nbody_ctx_state(c, &view);
+  if (int r = ap_scratch_reserve(c->stream, &view)) {  // so that a recorded step never allocates
     nbody_destroy(c);
     return r;
   }
@@ -162,16 +164,22 @@ extern "C" int nbody_ctx_state(nbody_ctx* c, nbody_state* out) {
 extern "C" int nbody_ctx_set_shard(nbody_ctx* c, uint32_t first, uint32_t count) {
   NB_ARG(c != nullptr, "ctx is NULL");
   NB_ARG(uint64_t(first) + uint64_t(count) <= uint64_t(c->n), "shard [%u, %u+%u) exceeds n=%u", first, first, count, c->n);
+  device_guard guard(c->device);
   c->first = first;
   c->count = count;
-  return NBODY_OK;
+  nbody_state view;
+  (void)nbody_ctx_state(c, &view);
+  return count ? ap_scratch_reserve(c->stream, &view) : int(NBODY_OK);  // the window's launch may need scratch the whole system's did not
 }
 
 extern "C" int nbody_ctx_configure_all_pairs(nbody_ctx* c, int split, int targets_per_thread, int source_path) {
   NB_ARG(c != nullptr, "ctx is NULL");
   if (int r = check_tuning(split, targets_per_thread, source_path)) return r;
   c->tuning = (split || targets_per_thread || source_path) ? NBODY_TUNING(split, targets_per_thread, source_path) : 0u;
-  return NBODY_OK;
+  device_guard guard(c->device);
+  nbody_state view;
+  (void)nbody_ctx_state(c, &view);
+  return view.count ? ap_scratch_reserve(c->stream, &view) : int(NBODY_OK);
 }
 
 extern "C" void* nbody_ctx_stream(nbody_ctx* c) { return c ? static_cast<void*>(c->stream) : nullptr; }

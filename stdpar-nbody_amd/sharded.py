@@ -140,8 +140,12 @@ class ShardedAllPairs:
         return x, outs[0], outs[1]
 
     def describe(self):
-        how = ("nbody_allgather_positions (" + ("ncclAllGather in place" if self.equal else "grouped ncclSend/ncclRecv") + ")"
-               if self.comm is not None else "torch.distributed all_gather over padded shards")
+        if self.world == 1 and self.comm is None:
+            how = "none (one rank, nothing is exchanged)"
+        elif self.comm is not None:
+            how = "nbody_allgather_positions (" + ("ncclAllGather in place" if self.equal else "grouped ncclSend/ncclRecv") + ")"
+        else:
+            how = "torch.distributed all_gather over padded shards"
         return f"rank shard {self.count} of {self.n} targets, exchange: {how}"
 
 

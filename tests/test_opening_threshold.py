@@ -58,7 +58,8 @@ def _check_pairs(oracle, nb, dtype, bw, theta):
         d2 = np.where(np.isnan(d2), np.inf, d2).astype(t)
         assert np.array_equal(oracle.can_approximate(dtype, bwf, theta, d2), vf < d2), k
     for _ in range(4):
-        d2 = (vf.astype(np.float64) * 10.0 ** rng.uniform(-3, 3, vf.size)).astype(t)
+        with np.errstate(over="ignore", under="ignore"):
+            d2 = (vf.astype(np.float64) * 10.0 ** rng.uniform(-3, 3, vf.size)).astype(t)
         assert np.array_equal(oracle.can_approximate(dtype, bwf, theta, d2), vf < d2)
 
 

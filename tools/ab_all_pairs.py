@@ -6,6 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 CASES = [("f64", "uniform", 65536), ("f64", "galaxy", 65536), ("f64", "uniform", 262144), ("f64", "galaxy", 262144),
          ("f64", "galaxy", 1 << 20), ("f32", "uniform", 262144), ("f32", "galaxy", 262144), ("f32", "uniform", 100000)]
+if os.environ.get("AB_CASES"):   # e.g. AB_CASES="f32:uniform:100000,f64:galaxy:65536"
+    CASES = [(a, b, int(c)) for a, b, c in (x.split(":") for x in os.environ["AB_CASES"].split(","))]
 
 
 def child(lib):

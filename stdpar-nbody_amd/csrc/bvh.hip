@@ -1599,7 +1599,7 @@ extern "C" int nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t
   NB_ALLOC(t->keys[1], sizeof(uint64_t) * size_t(n));
   NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
-  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(t->sort_blocks) + 1));  // + 256 digit totals
+  NB_ALLOC(t->hist, sizeof(uint32_t) * radix_sort_scratch_words(n));
   NB_ALLOC(t->tmp, tmp_bytes);
   NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));

@@ -2578,7 +2578,7 @@ extern "C" int nbody_octree_create_on(nbody_octree** out, int dtype, int dim, ui
   NB_ALLOC(t->keys[1], sizeof(uint64_t) * size_t(n));
   NB_ALLOC(t->idx[0], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
-  NB_ALLOC(t->hist, sizeof(uint32_t) * 256 * (size_t(radix_sort_blocks(n)) + 1));
+  NB_ALLOC(t->hist, sizeof(uint32_t) * radix_sort_scratch_words(n));
   NB_ALLOC(t->rootrec, 64);
   t->group_bytes = dtype == NBODY_F32 ? (dim == 3 ? sizeof(ot_group<float, 3>) : sizeof(ot_group<float, 2>))
                                       : (dim == 3 ? sizeof(ot_group<double, 3>) : sizeof(ot_group<double, 2>));

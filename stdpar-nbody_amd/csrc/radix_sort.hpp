@@ -1,6 +1,14 @@
-// Stable LSD radix sort of (u64 key, u32 index) pairs, 8 bits per pass — shared by the Hilbert BVH (K6, replaces
-// std::sort at src/bvh.h:55-94) and the octree build.  Per pass: per-block digit histogram, per-digit row scan,
-// stable scatter (wave match-any ranking; the 256-digit base scan is folded into the scatter kernel).
+// Sort of (u64 key, u32 index) pairs by (key, original position) — shared by the Hilbert BVH (K6, replaces std::sort at
+// src/bvh.h:55-94) and the octree build.  The order is total (positions are distinct), so every correct sort produces the same
+// permutation bit for bit; three forms, by size:
+//   * n <= 2048: all passes of a stable LSD radix sort in one launch (radix_sort_one_block_kernel);
+//   * up to 1.5 M pairs: a SPLITTER sort in five launches (round 4; 24 before): B - 1 splitters from a regular sample of the input
+//     sorted by one block, one counting pass + row scan + scatter into the B buckets (the "digit" of a pair is its bucket), then
+//     every bucket sorted by one block in LDS.  Buckets follow the data's own quantiles, so clustered keys (a galaxy inside a box
+//     inflated by escapers: most keys share their top 30 bits) cost nothing extra, and ties are broken by position, so equal keys
+//     cannot overfill a bucket;
+//   * beyond: stable LSD radix sort, 8 bits per pass (per-block digit histogram, per-digit row scan, stable scatter by wave
+//     match-any ranking with the 256-digit base scan folded in): 24 launches.
 // Kernels are `static` so both translation units can include this header.
 #pragma once
 #include "common.hpp"
@@ -230,8 +238,242 @@ static __global__ __launch_bounds__(kSortB) void radix_sort_one_block_kernel(uin
   }
 }
 
-// hist needs 256 * (nblk + 1) u32, nblk = radix_sort_blocks(n).  Sorts by key bits [0, key_bits): the pairs start in
-// (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.
+// ------------------------------------------------------------------------------------------------
+// Splitter sort (2048 < n <= kSplitterMaxN).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kSplitMaxBuckets = 2048;               // B <= 2048: splitters fit LDS (24 KB)
+constexpr uint32_t kSampleMax       = 4096;               // pairs the sample block sorts in LDS (48 KB)
+constexpr uint32_t kBucketCap       = 4096;               // pairs one block sorts in LDS (48 KB); larger buckets: slow global path
+constexpr uint32_t kSplitterMaxN    = 768u * kSplitMaxBuckets;  // average bucket <= 768: the largest stays far below the cap
+constexpr int kSampleThreads = 1024, kBucketThreads = 512;
+
+__host__ __device__ inline uint32_t splitter_sample(uint32_t B) { return 4u * B < kSampleMax ? 4u * B : kSampleMax; }  // power of two, >= 2 B
+__host__ __device__ inline uint32_t splitter_buckets(uint32_t n) {  // power of two, average bucket 384 .. 768
+  uint32_t b = 4;
+  while (b < kSplitMaxBuckets && uint64_t(b) * 768u < n) b <<= 1;
+  return b;
+}
+
+__device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) { return ka < kb || (ka == kb && ia < ib); }
+
+// Bitonic sorting network in the all-ascending ("flip / disperse") form over p[0 .. P), P a power of two, of which only the
+// first n hold pairs: the rest count as +infinity, and since every exchange leaves the smaller pair at the lower index an
+// exchange whose upper index is >= n is a no-op and is skipped.  K / V may be LDS or global pointers.  Pair number t of a stage
+// is handled by thread t mod NT, and the pairs 64 q .. 64 q + 63 of every stage whose exchanges span at most 128 elements touch
+// exactly the elements 128 q .. 128 q + 127: consecutive such stages are one wave's own business and need no block barrier
+// (P = 4096: 20 block barriers instead of 78 — the barriers were most of the kernels' time).  The caller has made the input
+// visible to the block; on return the output is.
+template <int NT, bool GLOBAL>
+__device__ __forceinline__ void bitonic_sort_pairs(uint64_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t P, uint32_t n) {
+  auto exchange = [&](uint32_t i, uint32_t j) {
+    if (j < n) {
+      const uint64_t ki = K[i], kj = K[j];
+      const uint32_t vi = V[i], vj = V[j];
+      if (pair_less(kj, vj, ki, vi)) {
+        K[i] = kj, V[i] = vj;
+        K[j] = ki, V[j] = vi;
+      }
+    }
+  };
+  bool prev_local = false;
+  auto sync = [&](bool local) {  // before a stage: its inputs were written by this wave alone iff it and the stage before are local
+    if (local && prev_local) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      if (GLOBAL) __threadfence_block();
+      __syncthreads();
+    }
+    prev_local = local;
+  };
+  for (uint32_t k = 2; k <= P; k <<= 1) {
+    const uint32_t half = k >> 1;
+    sync(!GLOBAL && k <= 128u);
+    for (uint32_t t = threadIdx.x; t < P / 2; t += NT) {  // flip: i against the mirror position in its k-block
+      const uint32_t base = (t / half) * k, r = t % half;
+      exchange(base + r, base + k - 1 - r);
+    }
+    for (uint32_t j = k >> 2; j >= 1; j >>= 1) {  // disperse
+      sync(!GLOBAL && j <= 64u);
+      for (uint32_t t = threadIdx.x; t < P / 2; t += NT) {
+        const uint32_t i = 2 * j * (t / j) + t % j;
+        exchange(i, i + j);
+      }
+    }
+  }
+  if (GLOBAL) __threadfence_block();
+  __syncthreads();
+}
+
+// S1: the splitters.  One block sorts m = splitter_sample(B) pairs taken at a regular stride from the input and keeps every
+// (m / B)-th one.  (Measured and not kept, round 4: ranking every sample pair against all others from LDS broadcasts instead of
+// sorting — no barriers, no dependent stages, any number of blocks — 28.8 us against 16 for m = 1024 and 115 against 53 for
+// m = 4096: three compares, two mask operations and two LDS reads per comparison cost more than the network's 66 round trips.)
+static __global__ __launch_bounds__(kSampleThreads) void splitter_sample_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B,
+                                                                                uint64_t* __restrict__ split_key,
+                                                                                uint32_t* __restrict__ split_idx) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const uint32_t m = splitter_sample(B), every = m / B;
+  uint64_t* K      = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* V      = reinterpret_cast<uint32_t*>(K + m);
+  for (uint32_t q = threadIdx.x; q < m; q += kSampleThreads) {
+    const uint32_t i = uint32_t((uint64_t(q) * n + n / 2) / m);  // < n
+    K[q]             = keys[i];
+    V[q]             = i;
+  }
+  bitonic_sort_pairs<kSampleThreads, false>(K, V, m, m);
+  for (uint32_t b = threadIdx.x + 1; b < B; b += kSampleThreads) {  // bucket b holds the pairs p with splitter[b-1] <= p < splitter[b]
+    split_key[b - 1] = K[every * b];
+    split_idx[b - 1] = V[every * b];
+  }
+}
+
+// bucket of a pair: the number of splitters <= it (splitters in LDS, B a power of two)
+__device__ __forceinline__ uint32_t bucket_of(const uint64_t* __restrict__ sk, const uint32_t* __restrict__ si, uint32_t B, uint64_t key,
+                                              uint32_t idx) {
+  uint32_t lo = 0;  // invariant: splitters [0, lo) are <= the pair, and the answer is < lo + step after each step
+  for (uint32_t step = B >> 1; step >= 1; step >>= 1) {
+    const uint32_t mid = lo + step;  // mid - 1 in [0, B - 2]
+    if (!pair_less(key, idx, sk[mid - 1], si[mid - 1])) lo = mid;
+  }
+  return lo;
+}
+
+// lanes of the wave holding the same bucket as this one (match-any over the log2(B) bits of the bucket number)
+__device__ __forceinline__ uint64_t same_bucket_lanes(uint32_t b, bool valid, int bits) {
+  uint64_t same = __ballot(valid);
+  for (int q = 0; q < bits; ++q) {
+    const bool bit      = (b >> q) & 1u;
+    const uint64_t vote = __ballot(valid && bit);
+    same &= bit ? vote : ~vote;
+  }
+  return same;
+}
+
+// S2: per-(bucket, block) counts; the bucket of every pair is kept (u16) for the scatter.
+template <int IPT>
+static __global__ __launch_bounds__(kSortB) void splitter_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
+                                                                       const uint64_t* __restrict__ split_key,
+                                                                       const uint32_t* __restrict__ split_idx,
+                                                                       uint32_t* __restrict__ hist, uint32_t nblk,
+                                                                       uint16_t* __restrict__ bucket_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint64_t* sk  = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* si  = reinterpret_cast<uint32_t*>(sk + B);
+  uint32_t* cnt = si + B;
+  for (uint32_t q = threadIdx.x; q < B; q += kSortB) {
+    if (q + 1 < B) sk[q] = split_key[q], si[q] = split_idx[q];
+    cnt[q] = 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    const uint64_t i = uint64_t(blockIdx.x) * (kSortB * IPT) + q * kSortB + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t b = valid ? bucket_of(sk, si, B, keys[i], uint32_t(i)) : 0u;
+    if (valid) bucket_out[i] = uint16_t(b);
+    const uint64_t same = same_bucket_lanes(b, valid, bits);  // one LDS atomic per distinct bucket of the strip
+    if (valid && (same & lt_mask) == 0ull) atomicAdd(&cnt[b], uint32_t(__popcll(same)));
+  }
+  __syncthreads();
+  for (uint32_t q = threadIdx.x; q < B; q += kSortB) hist[uint64_t(q) * nblk + blockIdx.x] = cnt[q];
+}
+
+// S4: scatter into the buckets (after radix_scan_rows_kernel over the B rows).  Order inside a bucket is whatever the LDS
+// atomics give: the bucket is sorted afterwards, and the sorted order is unique.
+template <int IPT>
+static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
+                                                                         const uint16_t* __restrict__ bucket_in,
+                                                                         const uint32_t* __restrict__ hist,
+                                                                         const uint32_t* __restrict__ totals, uint32_t nblk,
+                                                                         uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
+                                                                         uint32_t* __restrict__ bucket_start) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint32_t* base = reinterpret_cast<uint32_t*>(smem);  // [B]: where this block's pairs of a bucket go next
+  __shared__ uint32_t wsum[kSortB / 64];
+  __shared__ uint32_t carry;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t b0 = 0; b0 < B; b0 += kSortB) {  // exclusive scan of the bucket totals, kSortB at a time
+    const uint32_t q = b0 + threadIdx.x;
+    const uint32_t v = q < B ? totals[q] : 0u;
+    uint32_t inc     = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t o = __shfl_up(inc, off, 64);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t pre = carry;
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+    if (q < B) {
+      base[q] = pre + inc - v + hist[uint64_t(q) * nblk + blockIdx.x];
+      if (blockIdx.x == 0) bucket_start[q] = pre + inc - v;
+    }
+    __syncthreads();
+    if (threadIdx.x == kSortB - 1) carry = pre + inc;
+    __syncthreads();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) bucket_start[B] = n;
+  const uint64_t lt_mask = (1ull << lane) - 1ull;
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    const uint64_t i = uint64_t(blockIdx.x) * (kSortB * IPT) + q * kSortB + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t b = valid ? bucket_in[i] : 0u;
+    const uint64_t same = same_bucket_lanes(b, valid, bits);
+    uint32_t first = 0;
+    if (valid && (same & lt_mask) == 0ull) first = atomicAdd(&base[b], uint32_t(__popcll(same)));
+    first = __shfl(first, valid ? int(__builtin_ctzll(same)) : 0, 64);  // the strip's leader for this bucket
+    if (valid) {
+      const uint32_t pos = first + uint32_t(__popcll(same & lt_mask));
+      keys_out[pos]      = keys[i];
+      idx_out[pos]       = uint32_t(i);
+    }
+  }
+}
+
+// S5: one block per bucket sorts it — in LDS up to kBucketCap pairs, in place in global memory beyond (a bucket that large takes
+// an input whose regular sample misrepresents it; correct, slow) — and writes it to the output buffers at the same positions.
+// (The rank-by-comparison form of S1's note was measured here too: 217 us against 22-36 at N = 10^5, 592 against 77-102 at 10^6.)
+static __global__ __launch_bounds__(kBucketThreads) void splitter_bucket_sort_kernel(uint64_t* __restrict__ keys_in, uint32_t* __restrict__ idx_in,
+                                                                                     uint64_t* __restrict__ keys_out,
+                                                                                     uint32_t* __restrict__ idx_out,
+                                                                                     const uint32_t* __restrict__ bucket_start) {
+  __shared__ uint64_t K[kBucketCap];
+  __shared__ uint32_t V[kBucketCap];
+  const uint32_t start = bucket_start[blockIdx.x], cnt = bucket_start[blockIdx.x + 1] - start;
+  if (cnt == 0) return;
+  uint32_t P = 1;
+  while (P < cnt) P <<= 1;
+  if (cnt <= kBucketCap) {
+    for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) K[q] = keys_in[start + q], V[q] = idx_in[start + q];
+    bitonic_sort_pairs<kBucketThreads, false>(K, V, P, cnt);
+    for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) keys_out[start + q] = K[q], idx_out[start + q] = V[q];
+  } else {
+    bitonic_sort_pairs<kBucketThreads, true>(keys_in + start, idx_in + start, P, cnt);
+    for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) keys_out[start + q] = keys_in[start + q], idx_out[start + q] = idx_in[start + q];
+  }
+}
+
+// Scratch of a sort of n pairs, in u32 words: the count matrix (rows x blocks) + row totals, the bucket starts, the splitters
+// and the per-pair bucket numbers.  hist must hold radix_sort_scratch_words(n) words.
+constexpr uint32_t kSplitSmallN = 1u << 18;  // up to here the counting / scatter blocks take 512 pairs (more, smaller blocks), beyond 2048
+inline uint32_t splitter_blocks(uint32_t n) { return n <= kSplitSmallN ? (n + 511u) / 512u : (n + kSortTile - 1) / kSortTile; }
+inline size_t radix_sort_scratch_words(uint32_t n) {
+  const bool split  = n > kSortTile && n <= kSplitterMaxN;
+  const size_t nblk = split ? splitter_blocks(n) : (size_t(n) + kSortTile - 1) / kSortTile;
+  const size_t rows = split ? splitter_buckets(n) : 256;
+  return rows * (nblk + 1) + (rows + 1) + 3 * rows + (size_t(n) + 1) / 2 + 8;
+}
+
+// hist needs radix_sort_scratch_words(n) u32 (8-byte aligned).  Sorts by (key bits [0, key_bits), position): the pairs start in
+// (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.  Both buffers of
+// keys / idx are overwritten.
 inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 // Tried and not kept (round 3): taking the NEXT pass's histogram inside the scatter — it knows the block every key lands in —
 // with one global atomicAdd per key into three rotating histogram buffers (7 launches fewer per sort).  Bit-exact, but the
@@ -251,6 +493,34 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
     hipLaunchKernelGGL(radix_sort_one_block_kernel, dim3(1), dim3(kSortB), 0, st, keys[0], keys[1], idx[0], idx[1], n, key_bits);
     NB_HIP(hipGetLastError());
     *final_buf = ((key_bits + 7) / 8) & 1;
+    return NBODY_OK;
+  }
+  if (n <= kSplitterMaxN) {  // splitter sort: pairs start in (keys[0], position), go through (keys[1], idx[1]) bucketed, end in (keys[0], idx[0])
+    const uint32_t B = splitter_buckets(n), sblk = splitter_blocks(n);
+    int bits         = 0;
+    while ((1u << bits) < B) ++bits;
+    uint32_t* totals       = hist + size_t(B) * sblk;
+    uint32_t* bucket_start = totals + B;
+    uint32_t* split_idx    = bucket_start + B + 1;
+    uint64_t* split_key    = reinterpret_cast<uint64_t*>(split_idx + B + 1);  // 8-byte aligned: hist is, and B (sblk + 3) + 2 words is even
+    uint16_t* bucket       = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(split_key) + 2 * size_t(B));
+    hipLaunchKernelGGL(splitter_sample_kernel, dim3(1), dim3(kSampleThreads), splitter_sample(B) * 12u, st, keys[0], n, B, split_key, split_idx);
+    NB_HIP(hipGetLastError());
+    if (n <= kSplitSmallN)
+      hipLaunchKernelGGL(splitter_count_kernel<2>, dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
+    else
+      hipLaunchKernelGGL(splitter_count_kernel<kSortIPT>, dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(B), dim3(kSortB), 0, st, hist, sblk, totals);
+    NB_HIP(hipGetLastError());
+    if (n <= kSplitSmallN)
+      hipLaunchKernelGGL(splitter_scatter_kernel<2>, dim3(sblk), dim3(kSortB), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
+    else
+      hipLaunchKernelGGL(splitter_scatter_kernel<kSortIPT>, dim3(sblk), dim3(kSortB), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(splitter_bucket_sort_kernel, dim3(B), dim3(kBucketThreads), 0, st, keys[1], idx[1], keys[0], idx[0], bucket_start);
+    NB_HIP(hipGetLastError());
+    *final_buf = 0;
     return NBODY_OK;
   }
   int cur                = 0;

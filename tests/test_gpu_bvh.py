@@ -260,6 +260,77 @@ def test_sort_properties_at_full_size(nb):
     assert abs(root[3] - hs.m.sum()) <= 1e-9 * hs.m.sum()
 
 
+def _sorted_perm_check(nb, oracle, hs, ref):
+    """Keys of the state as it is (bit-exact vs the oracle), then the permutation against a stable argsort of those keys."""
+    dev = nb.DeviceSystem.from_host(hs)
+    st, t = dev.state(), dev.bvh
+    t.bounding_box(st, dev.stream)
+    t.hilbert_sort(st, dev.stream)
+    keys, perm = t.read(0, dev.stream), t.read(1, dev.stream)
+    olo, ohi = oracle.bounding_box(ref)
+    assert np.array_equal(keys, oracle.hilbert_keys(ref, olo, ohi))
+    assert np.array_equal(perm, np.argsort(keys, kind="stable").astype(np.uint32)), "permutation != stable argsort of the keys"
+    assert np.array_equal(perm, oracle.sort_keys(keys))
+    out = dev.download()
+    assert np.array_equal(out.x, hs.x[perm])
+    dev.close()
+    return keys
+
+
+@pytest.mark.parametrize("dim", [3, 2])
+def test_sort_forms_against_stable_argsort(nb, oracle, dim):
+    """K6 directly, at the sizes where its form changes (one block up to 2048 pairs; splitter sort above — bucket counts 4, 8, ...;
+    sample block, count / scan / scatter, bucket sorts), with equal keys (coincident bodies, bodies closer than a grid cell:
+    ties are broken by position) and on a nearly sorted input (what every step after the first sees)."""
+    rng = np.random.default_rng(11)
+    for n in (2, 3, 63, 64, 2047, 2048, 2049, 3000, 4096, 6145, 20000, 70001):
+        for variant in ("random", "ties", "presorted"):
+            hs = nb.HostSystem(1, dim, n)
+            x = rng.uniform(-3, 5, (n, dim))
+            if variant == "ties":  # a third of the bodies coincide with another one, a third sit within 1e-9 of one
+                src = rng.integers(0, n, n)
+                kind = rng.integers(0, 3, n)
+                x = np.where((kind == 0)[:, None], x[src], np.where((kind == 1)[:, None], x[src] + 1e-9 * rng.standard_normal((n, dim)), x))
+            hs.x[:], hs.m[:] = x, 1.0
+            ref = oracle.State(1, dim, n)
+            ref.x[:], ref.m[:] = hs.x, hs.m
+            if variant == "presorted":
+                olo, ohi = oracle.bounding_box(ref)
+                order = oracle.sort_keys(oracle.hilbert_keys(ref, olo, ohi))
+                hs.x[:] = hs.x[order]
+                k = max(1, n // 50)  # ... up to a few bodies that moved
+                hs.x[rng.integers(0, n, k)] = rng.uniform(-3, 5, (k, dim))
+                ref.x[:] = hs.x
+            keys = _sorted_perm_check(nb, oracle, hs, ref)
+            if variant == "ties" and n > 64:
+                assert len(np.unique(keys)) < n
+
+
+def test_sort_with_a_sample_that_misses_the_data(nb, oracle):
+    """The splitters come from a regular sample of the input.  Here every sampled position holds a body from one corner of the
+    box and every other position a body from the opposite corner: all splitters fall among the first, one bucket receives
+    everything else — more than a block ranks in LDS — and takes one of the slow paths.  Same permutation."""
+    for n in (30000, 3500):  # one bucket of ~29 700 pairs (in place in global memory); one of ~3 470 (the sorting network in LDS)
+        _sample_misses_the_data(nb, oracle, n)
+
+
+def _sample_misses_the_data(nb, oracle, n):
+    dim = 3
+    buckets = 4
+    while buckets < 2048 and buckets * 768 < n:
+        buckets *= 2
+    m = min(4 * buckets, 4096)
+    sampled = (np.arange(m, dtype=np.uint64) * n + n // 2) // m
+    rng = np.random.default_rng(5)
+    hs = nb.HostSystem(1, dim, n)
+    x = rng.uniform(50.0, 60.0, (n, dim))
+    x[sampled] = rng.uniform(-60.0, -50.0, (m, dim))
+    hs.x[:], hs.m[:] = x, 1.0
+    ref = oracle.State(1, dim, n)
+    ref.x[:], ref.m[:] = hs.x, hs.m
+    _sorted_perm_check(nb, oracle, hs, ref)
+
+
 def test_config4_n1e6_galaxy_theta05_vs_oracle(nb, oracle):
     """BASELINE config[3]: bvh 3D double N=1e6 galaxy theta=0.5 — the whole force phase against the oracle:
     bit-exact traversal counters for every body, force within tolerance."""

@@ -72,8 +72,10 @@ typedef struct nbody_state {
  * 2.0: nbody_state.tuning; the collective (nbody_comm_*), shard windows on contexts, per-device guards.
  * 2.1: nbody_bvh_create_on / nbody_octree_create_on (explicit device), nbody_octree_set_walk, nbody_octree_set_build, nbody_octree_set_step_budget,
  *      nbody_bvh_set_launch_order;
- *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)). */
-#define NBODY_HIP_ABI_VERSION 2001
+ *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)).
+ * 2.2: nbody_bvh_read what = 6 and nbody_bvh_opening_thresholds (the opening test as one compare), nbody_all_pairs_pair_rule;
+ *      the measured forms that are not shipped (traversal 3 / 4 / 6, octree build 2 / 4) are refused by this library. */
+#define NBODY_HIP_ABI_VERSION 2002
 int nbody_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -161,11 +163,11 @@ int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* s
  * input (body entries), +inf when no distance accepts.  For the tests that hold this form against src/bvh.h:246-248. */
 int nbody_bvh_opening_thresholds(int dtype, const void* width2, double theta, size_t n, void* out);
 int nbody_bvh_enable_counters(nbody_bvh* t, int on);
-/* K9 scheduling form: 0 = auto, 1 = one independent stackless walk per lane (the reference's loop as is),
- * 2 = wave-cooperative sweep of the union of the wave's walks in DFS key order (3 / 4: the compiler-scheduled step
- * program with 1 / 2 bodies per lane; 5: the step program written out as ISA — what 0 and 2 use; 6: four independent
- * 16-lane row sweeps per wave, a measured experiment without counters).  All forms make
- * every body perform the same tests in the same order: results and counters are bitwise identical. */
+/* K9 scheduling form: 0 = auto (by size), 1 = one independent stackless walk per lane — the reference's loop as is, with its
+ * product form of the opening test —, 2 (= 5) = wave-cooperative sweep of the union of the wave's walks in DFS key order, the step
+ * program written as ISA, the opening test as one compare against the record's threshold (nbody_bvh_read what = 6).  Both make
+ * every body perform the same tests in the same order: results and counters are bitwise identical (the tests hold them equal).
+ * Forms that were measured and lost (3 / 4 / 6) exist in the -DNBODY_EXPERIMENTS build only; this library refuses them. */
 int nbody_bvh_set_traversal(nbody_bvh* t, int mode);
 /* Launch order of the sweep: 0 = work items (groups that straddle a jump of the key order are cut in two and start first),
  * 1 = one block per group in index order.  Bitwise identical results; tests and tuning runs compare the two. */
@@ -190,11 +192,11 @@ int  nbody_octree_set_walk(nbody_octree* t, int mode);
  *   3 = one pass: every cell follows from the common key prefixes of neighbouring bodies, so all cells are numbered by one prefix
  *       sum and built at once (4 launches whatever the depth), and the multipoles take two or three (rank chunks, then the cells
  *       that span chunk boundaries, in two rounds above 2.6e5 bodies);
- *   1 = breadth-first, one launch per tree level for the build and one for the multipoles (21 + 21 in 3D);
- *   4 = as 1 for the levels the tree used at the last nbody_octree_info (+ 2), ONE launch behind a grid barrier for the rest;
- *   2 = every level behind the grid barrier (measured slower on MI355X).
- * 1, 2 and 4 number the sibling groups breadth-first, 3 in pre-order; the cells, their monopoles, the tree size and every
- * force and counter the walk produces are the same bit for bit. */
+ *   1 = breadth-first, one launch per tree level for the build and one for the multipoles (21 + 21 in 3D): the cross-check.
+ * 1 numbers the sibling groups breadth-first, 3 in pre-order; the cells, their monopoles, the tree size and every force and
+ * counter the walk produces are the same bit for bit.  A tree inserted by one form is not the other's to finish: changing the
+ * form clears the insert / tree state.  (The grid-barrier forms 2 and 4 — measured slower on MI355X — exist in the
+ * -DNBODY_EXPERIMENTS build only.) */
 int  nbody_octree_set_build(nbody_octree* t, int mode);
 /* Visit rounds one body's walk may make before it is abandoned and nbody_octree_info reports it (never spin on a damaged
  * tree).  0 = the default: the node pool size, which no walk of a well-formed tree reaches. */
@@ -245,6 +247,14 @@ int  nbody_ctx_set_shard(nbody_ctx* ctx, uint32_t first, uint32_t count);
 /* What K1 will launch for this view, e.g. "all_pairs_force_sgpr_kernel<double,3,R=2,JS=8> tile=512 pair=far3/near2"
  * (bench.py stamps its profiles with it). */
 int  nbody_all_pairs_describe(const nbody_state* s, char* out, size_t len);
+/* Which per-pair rounding form K1 (sz >= 32768) takes for this state — a property of the WHOLE system's extent, the same
+ * on every rank and for every shard window: *sparse_out = 1 when the bounding box of all sz positions (its volume, area in 2D,
+ * through *volume_out if not NULL) is at least 1.7e5 (6.4e4 in 2D); pairs at r^2 >= 4 then drop the eps term of
+ * m / (r^3 + eps), which is below an eighth of an ulp there (float: they take m r^-3 from the reciprocal square root alone).
+ * 0: the dense rule (always below 32768 bodies).
+ * Either form is within 2.5 ulp per term, but one body leaving a compact system can move a run from one to the other between
+ * two steps; tests and bitwise A/B runs query the rule in force with this call.  Blocking (one reduction + a 48-byte copy). */
+int  nbody_all_pairs_pair_rule(const nbody_state* s, void* stream, int* sparse_out, double* volume_out);
 
 /* ---- the collective: per-step all-gather of position shards (multi-GPU all-pairs; no reference counterpart) ------
  * RCCL over xGMI.  Partition fixed by the ABI: rank r of W owns bodies [sz*r/W, sz*(r+1)/W) (nbody_shard_range).

@@ -117,6 +117,15 @@ def calc_energies(s):
     return ke[0], pe[0]
 
 
+def calc_energies_wide(s):
+    """calc_energies with the same terms (formed in T) summed in double: the yardstick for float systems."""
+    ke, pe = C.c_double(), C.c_double()
+    r = lib().oracle_calc_energies_wide(s.dtype, s.dim, _p(s.m), _p(s.x), _p(s.v), C.c_double(s.c), C.c_uint32(s.n), C.byref(ke),
+                                        C.byref(pe))
+    assert r == 0
+    return ke.value, pe.value
+
+
 def bounding_box(s):
     t = np_dtype(s.dtype)
     lo, hi = np.zeros(s.dim, t), np.zeros(s.dim, t)

@@ -162,6 +162,14 @@ int oracle_calc_energies(int dtype, int dim, const void* m, const void* x, const
   return 0;
 }
 
+int oracle_calc_energies_wide(int dtype, int dim, const void* m, const void* x, const void* v, double c, uint32_t sz, double* ke,
+                              double* pe) {
+#define CALL(TT, S) calc_energies_wide_##S((const TT*)m, (const TT*)x, (const TT*)v, (TT)c, sz, ke, pe)
+  DISPATCH(dtype, dim, CALL);
+#undef CALL
+  return 0;
+}
+
 int oracle_bounding_box(int dtype, int dim, const void* x, uint32_t sz, void* xmin, void* xmax) {
 #define CALL(TT, S) bounding_box_##S((const TT*)x, sz, (TT*)xmin, (TT*)xmax)
   DISPATCH(dtype, dim, CALL);

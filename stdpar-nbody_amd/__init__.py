@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
     "nbody_comm_get_unique_id", "nbody_comm_create", "nbody_comm_create_all", "nbody_comm_destroy", "nbody_comm_world",
     "nbody_comm_rank", "nbody_comm_rccl_version", "nbody_shard_range", "nbody_comm_group_begin", "nbody_comm_group_end",
-    "nbody_allgather_positions", "nbody_bvh_opening_thresholds",
+    "nbody_allgather_positions", "nbody_bvh_opening_thresholds", "nbody_all_pairs_pair_rule",
 ]
 ABI_MAJOR = 2
 COMM_ID_BYTES = 128
@@ -150,6 +150,13 @@ def describe_all_pairs(st):
     buf = C.create_string_buffer(256)
     _check(lib().nbody_all_pairs_describe(C.byref(st), buf, C.c_size_t(256)))
     return buf.value.decode()
+
+
+def all_pairs_pair_rule(st, stream=None):
+    """(sparse, volume): the per-pair rounding form K1 takes for this state (nbody_all_pairs_pair_rule)."""
+    sparse, vol = C.c_int(), C.c_double()
+    _check(lib().nbody_all_pairs_pair_rule(C.byref(st), C.c_void_p(stream), C.byref(sparse), C.byref(vol)))
+    return bool(sparse.value), vol.value
 
 
 def shard_range(n, rank, world):

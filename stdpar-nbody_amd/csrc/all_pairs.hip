@@ -141,12 +141,8 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
       }
     }
   };
-  if constexpr (sizeof(T) == 8 || NBODY_F32_FFAR) {
-    if (ffar) run(std::true_type{});
-    else run(std::false_type{});
-  } else {
-    run(std::false_type{});
-  }
+  if (ffar) run(std::true_type{});
+  else run(std::false_type{});
 
   // combine the JS source-split partials in wave order, then a = c * sum
   if constexpr (JS > 1) {
@@ -178,7 +174,11 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
   }
 }
 
-// Scalar-stream form: pre-pass that packs (x, m) into aligned records, zero-mass padding up to a whole tile
+// Scalar-stream form: pre-pass that packs (x, m) into aligned records, zero-mass padding up to a whole tile.
+// (Measured and not kept, round 4: laying the records out in the order a wave reads them — one contiguous run per (chunk, slice),
+// so that the stream's next address is `+ 64 bytes` instead of ten scalar operations on the record number.  Bitwise the same
+// results, half the scalar instructions in the loop, and SLOWER: f32 N = 262 144 21.8 -> 22.5 ms dense, 19.3 -> 19.7 sparse — the
+// eight slices' streams of a block then start 128 KB apart and fall into the same sets of the 16 KB scalar cache.)
 template <typename T, int D>
 __global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                               src_rec<T, D>* __restrict__ out, uint32_t sz, uint32_t padded) {
@@ -241,12 +241,109 @@ __global__ __launch_bounds__(kBlock) void extent_kernel(const T* __restrict__ x,
 template <int JS>
 constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the scalar-stream form
 
+// One chunk of one target block, start to finish — the block shape of rounds 2-3, kept for single precision: the f32 source loop
+// is the tightest in the library (12 full-rate instructions and two transcendentals per pair) and anything around it shows: inside
+// the chunk-walking body below it runs 3-5 % slower although its instructions are the same (same instruction counts, same
+// scalar-cache hits, more cycles; VGPR banks do not matter: tools/microbench/vgpr_banks.hip), and the second copy of the loop that
+// the sparse rule needs costs the dense copy 5 % (N = 262 144: 20.85 -> 21.95 ms) while the galaxy gains 6 % (20.85 -> 19.3-19.7).
+// Measured alternatives, all worse for the dense cube (profiles/r04/ab_k1_f32_bodies*.txt): one kernel per rule, both launched, the
+// idle one's blocks returning at once (+ 7 %: 65 536 blocks dispatch at 22 ns each whatever they do); persistent blocks striding
+// over the chunks (+ 12 %).  chunk_sums == nullptr: the only chunk, `a` is written here.
+template <typename T, int D, int R, int JS>
+__device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restrict__ packed, const T* __restrict__ x, T* __restrict__ a, T c,
+                                                  uint32_t sz, uint32_t first, uint32_t count, uint32_t tiles_per_chunk, uint32_t tblock,
+                                                  uint32_t chunk, uint32_t tail_first, T* __restrict__ chunk_sums,
+                                                  const unsigned long long* __restrict__ ext, T* partial) {
+  using rec_t = src_rec<T, D>;
+  constexpr int TG  = kSgprWaves<JS> / JS;
+  constexpr int TB  = TG * 64 * R;
+  constexpr int SUB = kTileJ / JS;
+  const int lane   = threadIdx.x & 63;
+  const int wave   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int tgroup = wave / JS;
+  const int jpart  = wave % JS;
+  T xi[R][D], acc[R][D];
+  uint32_t ti[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    uint32_t local = tblock * TB + tgroup * (64 * R) + r * 64 + lane;
+    ti[r]          = local;
+    uint64_t i     = uint64_t(first) + (local < count ? local : 0u);
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+      xi[r][k]  = x[i * D + k];
+      acc[r][k] = T(0);
+    }
+  }
+  const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
+  const uint32_t t0     = chunk * tiles_per_chunk;
+  const uint32_t t1     = min(ntiles, t0 + tiles_per_chunk);
+  const pair_consts<T> pc;
+  const bool ffar       = ap_far_mode<D>(ext);
+  const uint32_t nsteps = (t1 - t0) * SUB;
+  constexpr int U = 64 / int(sizeof(rec_t));
+  struct batch_t {
+    rec_t r[U];
+  };
+  auto batch = [&](uint32_t k) { return packed + (uint64_t(t0 + k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
+  auto run = [&](auto ff) {
+    constexpr bool FF = decltype(ff)::value;
+    sgpr16 A = sload16(batch(0), xi[0][0]), B;
+    for (uint32_t k = 0; k < nsteps; k += 2 * U) {
+      swait(A, acc[0][0]);
+      B = sload16(batch(k + U), xi[0][0]);
+      {
+        const batch_t ba = __builtin_bit_cast(batch_t, A);
+        pair_batch<T, D, R, U, FF>(acc, xi, ba.r, pc);
+      }
+      swait(B, acc[0][0]);
+      A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);
+      {
+        const batch_t bb = __builtin_bit_cast(batch_t, B);
+        pair_batch<T, D, R, U, FF>(acc, xi, bb.r, pc);
+      }
+    }
+    swait(A, acc[0][0]);
+  };
+  if (ffar) run(std::true_type{});
+  else run(std::false_type{});
+  if constexpr (JS > 1) {
+    if (jpart > 0) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) partial[((((jpart - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane] = acc[r][k];
+    }
+    __syncthreads();
+    if (jpart == 0) {
+#pragma unroll
+      for (int p = 1; p < JS; ++p)
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+          for (int k = 0; k < D; ++k) acc[r][k] += partial[((((p - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane];
+    }
+  }
+  if (jpart == 0) {
+    T* out        = chunk_sums ? chunk_sums + (uint64_t(chunk) * (count - tail_first) - tail_first) * D : a;
+    const T scale = chunk_sums ? T(1) : c;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (ti[r] < count) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) out[uint64_t(ti[r]) * D + k] = scale * acc[r][k];
+      }
+    }
+  }
+}
+
 // Source chunks are a ROUNDING rule, not a launch shape: a target's result is c * (((s_0 + s_1) + s_2) + ...) with s_y the sum
 // over chunk y's tiles (its JS slice sums added in slice order).  A block either walks ALL chunks of its target block in order —
 // fresh accumulators per chunk, the slice combine per chunk, the running total in LDS — and writes `a` itself (no scratch, no
 // second kernel), or computes ONE s_y and stores it for combine_chunks_kernel.  Bitwise the same result either way; which
 // target blocks take which form is the launch plan's business (sgpr_launch_shape).
 // (one target per lane: 8 waves per SIMD, i.e. at most 64 VGPRs — hipcc's own allocation of the f64 3D instance is 66)
+// (one target per lane: 8 waves per SIMD, i.e. at most 64 VGPRs)
 template <typename T, int D, int R, int JS>
 __global__ __launch_bounds__(64 * kSgprWaves<JS>) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 1)))
 void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
@@ -275,6 +372,11 @@ void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
     tblock           = long_blocks + q % tail_blocks;
     y0               = q / tail_blocks;
     y1               = y0 + 1;
+  }
+  if constexpr (sizeof(T) == 4) {  // single precision: one chunk per block, in the block shape of rounds 2-3 (see sgpr_single_chunk)
+    sgpr_single_chunk<T, D, R, JS>(packed, x, a, c, sz, first, count, tiles_per_chunk, tblock, y0, long_blocks * TB,
+                                   direct ? static_cast<T*>(nullptr) : chunk_sums, ext, partial);
+    return;
   }
   const uint32_t tbase = tblock * TB + tgroup * (64 * R);
 #pragma unroll
@@ -377,12 +479,8 @@ void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
       }
     }
   };
-  if constexpr (sizeof(T) == 8 || NBODY_F32_FFAR) {
-    if (ffar) run(std::true_type{});
-    else run(std::false_type{});
-  } else {
-    run(std::false_type{});
-  }
+  if (ffar) run(std::true_type{});  // two copies of the loop: inside ONE loop hipcc hoists the rules' common head above the branch
+  else run(std::false_type{});
   if (jpart == 0 && direct) {  // all chunks walked here: acc holds the total
     int ln = lane;
     asm volatile("" : "+v"(ln));
@@ -565,12 +663,11 @@ int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out) {
   return rc;
 }
 
-// The bounding box of the whole system for ap_far_mode, stream-ordered before K1; nullptr ("dense") below kFarMinBodies
-// and in f32 (see NBODY_F32_FFAR).
+// The bounding box of the whole system for ap_far_mode, stream-ordered before K1; nullptr ("dense") below kFarMinBodies.
 template <typename T, int D>
 static int ap_extent(const nbody_state* s, hipStream_t st, const unsigned long long** out) {
   *out = nullptr;
-  if (s->sz < kFarMinBodies || (sizeof(T) == 4 && !NBODY_F32_FFAR)) return NBODY_OK;
+  if (s->sz < kFarMinBodies) return NBODY_OK;
   void* q = nullptr;
   if (int r = ap_scratch_get(st, 3, 64, &q)) return r;
   NB_HIP(hipMemsetAsync(q, 0xFF, 2 * D * sizeof(unsigned long long), st));
@@ -622,7 +719,7 @@ static sgpr_shape sgpr_launch_shape(const nbody_state* s, const k1_plan& plan) {
   sh.long_blocks = blocks;
   if (plan.chunks <= 1 || blocks == 0) return sh;
   const uint32_t slots = resident_blocks(reinterpret_cast<const void*>(&all_pairs_force_sgpr_kernel<T, D, R, JS>), 64 * kSgprWaves<JS>);
-  uint32_t tail        = blocks >= 4u * slots ? slots : blocks;
+  uint32_t tail        = sizeof(T) == 8 && blocks >= 4u * slots ? slots : blocks;  // f32: one chunk per block throughout (sgpr_single_chunk)
   if (const char* e = experiment_env("NBODY_K1_TAIL")) tail = uint32_t(atoi(e));  // -DNBODY_EXPERIMENTS builds: A/B runs (target blocks in the tail)
   sh.tail_blocks = tail < blocks ? tail : blocks;
   sh.long_blocks = blocks - sh.tail_blocks;
@@ -649,7 +746,7 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
   auto* packed = static_cast<src_rec<T, D>*>(scratch);
   const uint64_t grid = uint64_t(sh.long_blocks) + uint64_t(sh.tail_blocks) * plan.chunks;
   NB_ARG(grid < (1ull << 31), "all-pairs: %llu blocks exceed the grid limit", (unsigned long long)grid);
-  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(uint32_t(grid)), dim3(64 * kSgprWaves<JS>), 0, st, packed,
+hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(uint32_t(grid)), dim3(64 * kSgprWaves<JS>), 0, st, packed,
                      static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
                      plan.tiles_per_chunk, plan.chunks, sh.long_blocks, sh.tail_blocks, sums, ext);
   NB_HIP(hipGetLastError());
@@ -729,7 +826,8 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
   k1_plan p;
   if (int rc = plan_all_pairs<T>(s, &p)) return rc;
   const char* t = sizeof(T) == 8 ? "double" : "float";
-  const char* pair = sizeof(T) == 4 ? "rsq+rcp" : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3";
+  const char* pair = sizeof(T) == 4 ? (s->sz >= kFarMinBodies ? "rsq+rcp[m y^3 at r2 >= 4 if sparse]" : "rsq+rcp")
+                                    : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3";
   sgpr_shape sh;
   uint32_t tb = 0;
   if (all_pairs_shape<T, D>(s, p, &sh, &tb)) {
@@ -958,10 +1056,6 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
 #pragma unroll
                 for (int q = 0; q < KS; q += NB) pair_accumulate_far<D, NB>(pt, xg[tt], &src[q], lowest, pc.k15, pc.k1875);
               }
-            } else if constexpr ((NBODY_F32_PAIR & 3) != 0) {
-              constexpr int G = NBODY_K2_TIER_G < KS ? NBODY_K2_TIER_G : KS;
-#pragma unroll
-              for (int q = 0; q < KS; q += G) pair_accumulate_tier<D, G>(pt, xg[tt], &src[q]);
             } else {
 #pragma unroll
               for (int q = 0; q < KS; q += NB) pair_accumulate_multi<T, D, NB>(pt, xg[tt], &src[q]);
@@ -1090,6 +1184,26 @@ extern "C" int nbody_all_pairs_describe(const nbody_state* s, char* out, size_t 
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using TG = decltype(tg);
     return all_pairs_describe<typename TG::type, TG::dim>(s, out, len);
+  });
+}
+
+extern "C" int nbody_all_pairs_pair_rule(const nbody_state* s, void* stream, int* sparse_out, double* volume_out) {
+  NB_ARG(sparse_out != nullptr, "sparse_out is NULL");
+  if (int r = check_state(s)) return r;
+  device_guard guard(stream_device(as_stream(stream)));
+  *sparse_out = 0;
+  if (volume_out) *volume_out = 0.0;
+  return dispatch(s->dtype, s->dim, [&](auto tg) {
+    using T         = typename decltype(tg)::type;
+    constexpr int D = decltype(tg)::dim;
+    const unsigned long long* ext = nullptr;
+    if (int r = ap_extent<T, D>(s, as_stream(stream), &ext)) return r;
+    if (ext == nullptr) return int(NBODY_OK);  // below kFarMinBodies: the dense rule by definition
+    unsigned long long host[2 * D];
+    NB_HIP(hipMemcpyAsync(host, ext, sizeof host, hipMemcpyDeviceToHost, as_stream(stream)));
+    NB_HIP(hipStreamSynchronize(as_stream(stream)));
+    *sparse_out = ap_far_rule<D>(host, volume_out) ? 1 : 0;
+    return int(NBODY_OK);
   });
 }
 

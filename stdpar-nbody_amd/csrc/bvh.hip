@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-// K9, wave-cooperative form.
+// K9, wave-cooperative sweep (the idea; bvh_force_sweep_isa_kernel below is the shipped form of it).
 //
 // Every lane still performs exactly the reference's own sequence of node tests / body terms, in its own order,
 // with its own decisions (results and counters are bitwise those of bvh_force_kernel).  What changes is WHEN: a
@@ -606,31 +606,6 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
 // pipelining the next record's load ahead of the accumulation as in the per-lane kernel.
 // Packed key = covered << 5 | level, so this form needs nlevels <= 26.
 // ------------------------------------------------------------------------------------------------
-template <typename T>
-struct rec_sgprs;
-template <>
-struct rec_sgprs<double> {
-  typedef uint32_t type __attribute__((ext_vector_type(16)));
-  __device__ static __forceinline__ type load(const void* base, uint32_t off) {  // base, off wave-uniform
-    type r;
-    asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(r) : "s"(base), "s"(off));
-    return r;
-  }
-};
-template <>
-struct rec_sgprs<float> {
-  typedef uint32_t type __attribute__((ext_vector_type(8)));
-  __device__ static __forceinline__ type load(const void* base, uint32_t off) {
-    type r;
-    asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(r) : "s"(base), "s"(off));
-    return r;
-  }
-};
-template <typename V>
-__device__ __forceinline__ void rec_wait(V& v) {
-  asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(v));
-}
-
 // Work items of the sweep.  A wave's sweep is 2.9k-14.2k steps long (config 4: mean 7.4k, p90 9.0k); the longest belong to
 // the ~1-2 % of groups whose 64 consecutive bodies straddle a jump of the reference's key order (bounding-box diagonals of
 // 20-70 length units against a median of 5): their unions are 2-3.5x a body's walk.  A SIMD slot runs only about two waves
@@ -738,251 +713,9 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
   }
 }
 
-// BPL bodies per lane: the wave sweeps the union of 64 * BPL consecutive (Hilbert-adjacent) bodies' walks.  The union
-// grows slowly with the group (about 7.4k entries for 64 bodies, 8k for 128 at config 4) while the scalar half of a step —
-// load, successors, position update: as many issue slots as the vector half — is paid once per step, and the BPL
-// independent per-body chains give the wave instruction-level parallelism.
-template <typename T, int D, int BPL, bool COUNT>
-__global__ __launch_bounds__(64) void bvh_force_wave_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
-                                                            const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
-                                                            uint32_t count, T theta2, uint32_t nlevels,
-                                                            uint32_t* __restrict__ counters, const uint32_t* __restrict__ items,
-                                                            const uint32_t* __restrict__ nitems, uint32_t stride, uint32_t parts) {
-  constexpr uint32_t DONE = 0xffffffffu;
-  constexpr uint32_t RB   = uint32_t(sizeof(tree_rec<T>));  // 64 (f64) or 32 (f32) bytes per entry
-  // work item of this block: with an item list, the XCD it runs on (block index mod 8) owns one list (bvh_items_kernel)
-  uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x), lane_lo = 0, lane_hi = 63;
-  if (items) {
-    const uint32_t xcd = blockIdx.x % 8u, slot = blockIdx.x / 8u;
-    if (slot >= nitems[xcd]) return;
-    const uint32_t it = items[xcd * stride + slot];
-    group   = it & 0xfffffu;
-    lane_lo = (it >> 20) & 63u;
-    lane_hi = it >> 26;
-  } else if (parts > 1u) {  // every group as `parts` equal lane ranges (small systems: see force_run)
-    lane_lo = (group % parts) * (64u / parts);
-    lane_hi = lane_lo + 64u / parts - 1u;
-    group /= parts;
-  }
-  const uint32_t base = group * (64u * BPL) + threadIdx.x;
-  const pair_consts<T> pc;
-  T xs[BPL][D], acc[BPL][D];
-  uint32_t key[BPL], bi[BPL];
-  bool valid[BPL];
-  // A lane's key keeps counting past the end (covered >= sz means finished: such keys compare above every live
-  // one because `covered` sits in the high bits), so only lanes outside the shard need a sentinel.
-#pragma unroll
-  for (int b = 0; b < BPL; ++b) {
-    const uint32_t local = base + 64u * b;
-    valid[b]             = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
-    bi[b]                = first + (valid[b] ? local : 0u);
-    key[b]               = valid[b] ? 0u : DONE;  // root: covered 0, level 0
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      xs[b][k]  = x[uint64_t(bi[b]) * D + k];
-      acc[b][k] = T(0);
-    }
-  }
-  uint32_t c_nodes[BPL] = {}, c_leaf[BPL] = {}, c_mono[BPL] = {}, c_body[BPL] = {};
-
-  // wave-uniform position of the sweep, kept incrementally in SGPRs: packed key, levels below, byte offset of the record
-  // packed key, 32 << (levels below the entry), byte offset of the record
-  uint32_t cur = 0, span = 32u << nlevels, off = 0;
-  // cur >= (sz << 5): covered >= sz, every remaining key is >= cur: all lanes are finished.  One less, because an accepted
-  // ROOT (theta > 0.58) is left by the ascend rule with covered + 2^nlevels and level - 1 = 31 after the borrow, which is
-  // (sz << 5) - 1 when sz is a power of two; no live key has level 31.
-  const uint32_t end_key = (sz << 5) - 1u;
-#pragma unroll
-  for (int b = 0; b < BPL; ++b)
-#pragma unroll
-    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(xs[b][k]));  // the position loads complete here, not inside the loop
-
-  while (cur < end_key) {
-    auto raw = rec_sgprs<T>::load(node, off);  // wave-uniform address: one scalar load of the whole record
-    // the two possible successors while the load is in flight
-    // left child -> sibling (same level); right child -> parent + 1 (level - 1)   (src/bvh.h:272-281)
-    // (an entry is a right child iff its level-order index is even; the root counts as one)
-    const uint32_t right = ((off / RB) & 1u) ^ 1u;
-    const uint32_t ka    = cur + span - right;  // covered + 2^(levels below), level - right
-    const uint32_t kd    = cur + 1u;            // descend: same covered, level + 1  (src/bvh.h:283-286)
-    const bool body      = span == 32u;         // (counters only: body records pass the opening test by construction)
-    rec_wait(raw);
-    const tree_rec<T> rc = __builtin_bit_cast(tree_rec<T>, raw);
-    uint64_t m_reject_any = 0ull, waiting = 0ull;
-#pragma unroll
-    for (int b = 0; b < BPL; ++b) {
-      T d[D];
-#pragma unroll
-      for (int k = 0; k < D; ++k) d[k] = xs[b][k] - rc.v[k];
-      const T d2 = dist2_ref<T, D>(d);
-      // a body is always taken (src/bvh.h:288-300), a node if it passes the opening test (src/bvh.h:306)
-      T scaled;
-      {
-#pragma clang fp contract(off)
-        scaled = theta2 * d2;
-      }
-      // the conditions as scalar masks from ballots of the two plain compares; lanes read them back for free
-      const uint64_t m_active = __builtin_amdgcn_ballot_w64(key[b] == cur);
-      const uint64_t m_approx = __builtin_amdgcn_ballot_w64(!(rc.v[D + 2] >= scaled));  // `<` for numbers; NaN accepts
-      const uint64_t m_accept = m_active & m_approx;
-      const uint64_t m_reject = m_active & ~m_approx;
-      const bool accept       = __builtin_amdgcn_inverse_ballot_w64(m_accept);
-      const bool reject       = __builtin_amdgcn_inverse_ballot_w64(m_reject);
-      if (COUNT) {
-        const bool active = __builtin_amdgcn_inverse_ballot_w64(m_active);
-        const bool approx = __builtin_amdgcn_inverse_ballot_w64(m_approx);
-        if (active) {
-          const uint32_t cov = cur >> 5;
-          if (body) {
-            c_body[b] += (cov != bi[b]);
-            c_leaf[b] += !(cov & 1u);  // one leaf visit per body pair, counted at its first body
-          } else {
-            ++c_nodes[b];
-            c_mono[b] += approx;
-          }
-        }
-      }
-      if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc[b], d, d2, rc.v[D], pc);
-      key[b] = accept ? ka : (reject ? kd : key[b]);
-      m_reject_any |= m_reject;
-      waiting |= __builtin_amdgcn_ballot_w64(key[b] < ka);
-    }
-    // Next position, branch-free in the common cases (every branch costs the wave an issue slot and a refetch).
-    // A lane opened the node: its left child is the smallest key any lane can now hold.  Otherwise follow the ascend rule
-    // (parent + 1 = idx / 2 for an even idx; sibling = idx + 1) — unless some lane waits at a smaller key: it jumped there
-    // from a deeper subtree, to an entry below the one just accepted by the others (rare; found and decoded below).
-    const uint32_t off_down = 2u * off + RB, off_up = right ? (off >> 1) : off + RB;
-    const uint32_t sh_down = span >> 1, sh_up = span << right;
-    uint64_t behind;
-    // four scalar selects on one condition; written out because hipcc turns the equivalent C++ into a diamond of branches
-    asm volatile("s_cmp_lg_u64 %[mr], 0\n\t"
-                 "s_cselect_b32 %[cur], %[kd], %[ka]\n\t"
-                 "s_cselect_b32 %[off], %[od], %[ou]\n\t"
-                 "s_cselect_b32 %[sh], %[sd], %[su]\n\t"
-                 "s_cselect_b64 %[bh], 0, %[wt]"
-                 : [cur] "=&s"(cur), [off] "=&s"(off), [sh] "=&s"(span), [bh] "=&s"(behind)
-                 : [mr] "s"(m_reject_any), [kd] "s"(kd), [ka] "s"(ka), [od] "s"(off_down), [ou] "s"(off_up), [sd] "s"(sh_down),
-                   [su] "s"(sh_up), [wt] "s"(waiting)
-                 : "scc");
-    if (__builtin_expect(behind != 0ull, 0)) {
-      uint32_t cand = ka;
-      for (bool again = true; again;) {  // the smallest key any body of the wave holds
-        again = false;
-#pragma unroll
-        for (int b = 0; b < BPL; ++b) {
-          uint64_t m = __builtin_amdgcn_ballot_w64(key[b] < cand);
-          while (m) {
-            cand  = __builtin_amdgcn_readlane(key[b], __builtin_ctzll(m));
-            m     = __builtin_amdgcn_ballot_w64(key[b] < cand);
-            again = BPL > 1;
-          }
-        }
-      }
-      cur                  = cand;
-      const uint32_t level = cand & 31u;
-      const uint32_t shift = nlevels - level;
-      span                 = 32u << shift;
-      off                  = (((1u << level) - 1u) + ((cand >> 5) >> shift)) * RB;
-    }
-    cur = __builtin_amdgcn_readfirstlane(cur);  // wave-uniform by construction; keep it in an SGPR
-  }
-#pragma unroll
-  for (int b = 0; b < BPL; ++b) {
-    if (valid[b]) {
-      const uint32_t local = base + 64u * b;
-#pragma unroll
-      for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[b][k];
-      if (COUNT) {
-        counters[uint64_t(bi[b]) * 4 + 0] = c_nodes[b];
-        counters[uint64_t(bi[b]) * 4 + 1] = c_leaf[b];
-        counters[uint64_t(bi[b]) * 4 + 2] = c_mono[b];
-        counters[uint64_t(bi[b]) * 4 + 3] = c_body[b];
-      }
-    }
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K9, row sweeps: FOUR independent sweeps per wave, one per 16-lane row (traversal mode 6; an experiment that is kept because
-// its measurement is: profiles/r03/k9_row_sweep.txt).  The union of 16 Hilbert-adjacent walks is 23 % shorter than the union of
-// 64 (5.7k against 7.4k entries at config 4), but a row's position is no longer wave-uniform: the record comes through the
-// vector memory path (one address per row), the position lives in VGPRs, the row-wide conditions are cut out of ballots per
-// lane, and every scalar operation of the wave sweep's bookkeeping becomes a vector one.  Same tests in the same order per
-// body: bitwise the results of every other form.
-// ------------------------------------------------------------------------------------------------
-template <typename T, int D>
-__global__ __launch_bounds__(64) void bvh_force_row_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
-                                                           const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
-                                                           uint32_t count, T theta2, uint32_t nlevels) {
-  const uint32_t group = xcd_contiguous_block(blockIdx.x, gridDim.x);
-  const uint32_t local = group * 64u + threadIdx.x;
-  const bool valid     = local < count;
-  const uint32_t bi    = first + (valid ? local : 0u);
-  const pair_consts<T> pc;
-  T xs[D], acc[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    xs[k]  = x[uint64_t(bi) * D + k];
-    acc[k] = T(0);
-  }
-  uint32_t key = valid ? 0u : 0xffffffffu;
-  // the row's position, the same value in its 16 lanes: packed key, 32 << (levels below), level-order index of the entry
-  uint32_t cur = 0, span = 32u << nlevels, idx = 0;
-  const uint32_t end_key = (sz << 5) - 1u;  // see bvh_force_wave_kernel
-  const uint32_t rshift  = threadIdx.x & 48u;
-  uint32_t budget        = (4u << nlevels) + 64u;  // a sweep visits every tree entry at most once: an exit every wave reaches
-  while (__builtin_amdgcn_ballot_w64(cur < end_key) != 0ull && budget-- != 0u) {
-    const bool live      = cur < end_key;
-    const tree_rec<T> rc = node[live ? idx : 0u];
-    const uint32_t right = (idx & 1u) ^ 1u;     // an entry is a right child iff its level-order index is even (root included)
-    const uint32_t ka = cur + span - right, kd = cur + 1u;
-    T d[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) d[k] = xs[k] - rc.v[k];
-    const T d2 = dist2_ref<T, D>(d);
-    T scaled;
-    {
-#pragma clang fp contract(off)
-      scaled = theta2 * d2;
-    }
-    const bool active = live && key == cur;
-    const bool approx = !(rc.v[D + 2] >= scaled);
-    const bool accept = active && approx, reject = active && !approx;
-    const uint64_t m_accept = __builtin_amdgcn_ballot_w64(accept);
-    if (m_accept != 0ull) tree_accumulate<T, D>(accept, m_accept, acc, d, d2, rc.v[D], pc);
-    key = accept ? ka : (reject ? kd : key);
-    const bool row_reject = ((__builtin_amdgcn_ballot_w64(reject) >> rshift) & 0xffffull) != 0ull;
-    const bool row_wait   = ((__builtin_amdgcn_ballot_w64(live && key < ka) >> rshift) & 0xffffull) != 0ull;
-    uint32_t mn = key;  // smallest key of the row (needed only when the row is behind; rows take their branches together)
-    if (__builtin_amdgcn_ballot_w64(live && !row_reject && row_wait) != 0ull) {
-#pragma unroll
-      for (int o = 8; o > 0; o >>= 1) {
-        const uint32_t other = uint32_t(__shfl_xor(int(mn), o, 16));
-        mn                   = other < mn ? other : mn;
-      }
-    }
-    if (live) {
-      if (row_reject) {  // some lane of the row opened the entry: its left child is the smallest key the row can hold
-        cur = kd;
-        idx = 2u * idx + 1u;
-        span >>= 1;
-      } else if (!row_wait) {  // ascend rule: left child -> sibling, right child -> parent + 1
-        cur = ka;
-        idx = right ? (idx >> 1) : idx + 1u;
-        span <<= right;
-      } else {  // a lane waits below the entry just left
-        cur                  = mn;
-        const uint32_t level = mn & 31u, shift = nlevels - level;
-        span                 = 32u << shift;
-        idx                  = ((1u << level) - 1u) + ((mn >> 5) >> shift);
-      }
-    }
-  }
-  if (valid) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) a[uint64_t(local) * D + k] = c * acc[k];
-  }
-}
+#ifdef NBODY_EXPERIMENTS
+#include "experiments/bvh_forms.inc"  // traversal modes 3, 4, 6: measured forms that are not shipped
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // K9, the sweep's step program written out as ISA (f64 described; the f32 text follows the same skeleton).
@@ -1453,6 +1186,7 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const uint32_t crossover = sizeof(T) == 8 ? 4096u : 180000u;
   int traversal = t->traversal;
   if (const char* e = experiment_env("NBODY_K9_MODE"); e && traversal == 0) traversal = atoi(e);  // -DNBODY_EXPERIMENTS builds only
+#ifdef NBODY_EXPERIMENTS
   if (traversal == 6) {  // four 16-lane row sweeps per wave (experiment; no counters)
     if (t->counters_on || t->nlevels > 26) {
       set_error("traversal mode 6 (row sweeps) has no counters and needs nlevels <= 26");
@@ -1464,18 +1198,17 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     NB_HIP(hipGetLastError());
     return NBODY_OK;
   }
+#endif
   const bool wave = traversal >= 2 || (traversal == 0 && t->nlevels <= 26 && s->count >= crossover);
   if (wave && t->nlevels > 26) {
     set_error("wave-cooperative traversal needs nlevels <= 26 (n <= 2^26), tree has %u levels", t->nlevels);
     return NBODY_ERR_ARG;
   }
-  // Bodies per lane of the sweep: 1.  With 2 (128 bodies per wave: half the waves, the scalar half of every step shared)
-  // config 4 takes 12.2 ms against 9.55 — the union of 128 walks is that much longer than the union of 64.  Traversal
-  // mode 4 still selects it (tests keep it bitwise equal to the other forms); 3 forces 1.
-  const int bpl            = traversal == 4 ? 2 : 1;
-  // The step program written out as ISA (bvh_force_sweep_isa_kernel) is the sweep that auto and 2 select; 5 forces it, 3 keeps
-  // the compiler-scheduled form.  All forms are bitwise identical.
-  const bool isa = wave && (traversal == 0 || traversal == 2 || traversal == 5);
+  // The sweep is the step program written out as ISA (bvh_force_sweep_isa_kernel: auto, 2, 5).  The -DNBODY_EXPERIMENTS build also
+  // has the compiler-scheduled step (3; with 2 bodies per lane: 4 — 128 bodies per wave, config 4 12.2 ms against 9.55) and the
+  // row sweeps (6).  All forms are bitwise identical.
+  const int bpl  = traversal == 4 ? 2 : 1;
+  [[maybe_unused]] const bool isa = wave && (traversal == 0 || traversal == 2 || traversal == 5);
   const uint32_t per_block = wave ? 64u * uint32_t(bpl) : 64u;
   const uint32_t blocks    = (s->count + per_block - 1) / per_block;
 #define NB_ARGS                                                                                                   \
@@ -1519,19 +1252,22 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 #define NB_WARGS                                                                                                             \
   dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
    s->first, s->count, th2, t->nlevels, t->counters, items, nitems, stride, parts
+#ifdef NBODY_EXPERIMENTS
   if (wave && bpl == 2) {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, true>), NB_WARGS);
     else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 2, false>), NB_WARGS);
-  } else if (wave && isa) {
+  } else if (wave && !isa) {
+    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
+    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
+  } else
+#endif
+  if (wave) {
 #define NB_IARGS                                                                                                             \
   dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
    s->first, s->count, t->nlevels, t->counters, items, nitems, stride, parts
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, true>), NB_IARGS);
     else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_IARGS);
 #undef NB_IARGS
-  } else if (wave) {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, true>), NB_WARGS);
-    else hipLaunchKernelGGL((bvh_force_wave_kernel<T, D, 1, false>), NB_WARGS);
   } else {
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
     else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
@@ -1641,7 +1377,12 @@ extern "C" int nbody_bvh_enable_counters(nbody_bvh* t, int on) {
 
 extern "C" int nbody_bvh_set_traversal(nbody_bvh* t, int mode) {
   NB_ARG(t != nullptr, "nbody_bvh is NULL");
-  NB_ARG(mode >= 0 && mode <= 6, "traversal mode must be 0 (auto), 1 (per-lane), 2 (wave-cooperative), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 5 (hand-scheduled sweep), 6 (four 16-lane row sweeps per wave), got %d", mode);
+#ifdef NBODY_EXPERIMENTS
+  NB_ARG(mode >= 0 && mode <= 6, "traversal mode must be 0 (auto), 1 (per-lane), 2 / 5 (wave-cooperative sweep), 3 / 4 (compiler-scheduled sweep with 1 / 2 bodies per lane), 6 (four 16-lane row sweeps per wave), got %d", mode);
+#else
+  NB_ARG(mode == 0 || mode == 1 || mode == 2 || mode == 5, "traversal mode must be 0 (auto), 1 (per-lane walks) or 2 (wave-cooperative sweep; 5 is the same), got %d%s", mode,
+         mode == 3 || mode == 4 || mode == 6 ? " — that form exists only in the -DNBODY_EXPERIMENTS build (make experiments)" : "");
+#endif
   t->traversal = mode;
   return NBODY_OK;
 }
@@ -1666,6 +1407,7 @@ extern "C" int nbody_bvh_bounding_box(nbody_bvh* t, const nbody_state* s, void* 
 
 extern "C" int nbody_bvh_get_bounding_box(nbody_bvh* t, void* xmin_out, void* xmax_out, void* stream) {
   NB_ARG(t != nullptr && xmin_out && xmax_out, "NULL argument");
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_bvh")) return r;
   device_guard guard(t->device);
   if (!t->have_bbox) {
     set_error("nbody_bvh_get_bounding_box before nbody_bvh_bounding_box");
@@ -1733,6 +1475,7 @@ extern "C" int nbody_bvh_opening_thresholds(int dtype, const void* width2, doubl
 
 extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t bytes, void* stream) {
   NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_bvh")) return r;
   device_guard guard(t->device);
   const size_t D = size_t(t->dim);
   hipStream_t st = as_stream(stream);

@@ -204,20 +204,6 @@ struct pair_math<double> {
   }
 };
 
-// NBODY_F32_PAIR selects the f32 pair weight of K1 (and K2's NB = 1 chains): 0 = v_rsq_f32 + v_rcp_f32 (3 full-rate ops + 2
-// transcendentals), 1 / 2 = the reciprocal-free far form with the eps expansion to first / second order and a guarded near
-// path, + 4 = an eps-free form when a whole batch has r2 >= 4.  Measured at config 3 and on the galaxy in profiles/r03/
-// f32_pair_forms.txt; the default is what that table says is fastest.
-#ifndef NBODY_F32_PAIR
-  #define NBODY_F32_PAIR 0
-#endif
-// NBODY_F32_FFAR = 1 compiles the sparse-system rule (m y^3 for r2 >= 4) into the f32 kernels too.  Measured A/B on one box
-// (profiles/r03/f32_pair_forms.txt): galaxy N = 262 144 21.17 -> 20.65 ms, but the dense loop of the same kernel 21.23 -> 21.74 ms;
-// shipped off — f32 K1 is then instruction for instruction round 2's kernel.
-#ifndef NBODY_F32_FFAR
-  #define NBODY_F32_FFAR 0
-#endif
-
 template <>
 struct pair_math<float> {
   static constexpr float tiny = 1e-37f;
@@ -230,24 +216,10 @@ struct pair_math<float> {
     float d3 = __builtin_fmaf(r2, r2 * y0, FLT_EPSILON);
     return __builtin_amdgcn_rcpf(d3) * mj;
   }
-  // Without the reciprocal: with u = r2^(-3/2) = y^3 (y = v_rsq_f32(r2), 1 ulp),
-  //     mj / (r2^(3/2) + eps) = mj u / (1 + eps u) = mj u (1 - q + q^2 - ...),  q = eps u.
-  // ORDER 1 keeps 1 - q: the dropped q^2 is below 2^-26 (a quarter of an ulp) for q <= 2^-13, i.e. r2 >= 2^-6.67 — threshold 2^-6;
-  // ORDER 2 keeps 1 - q + q^2: q^3 <= 2^-26 for r2 >= 2^-9.6 — threshold 2^-9.  eps is FLT_EPSILON or, where a mixed batch lets
-  // each lane choose by its own r2 (>= 4: eps u <= 2^-26), 0: fma(my, +0, my) == my bit for bit.
-  static constexpr uint32_t far_bits = 0x40800000u;                                    // 4.0f
-  template <int ORDER>
-  static constexpr uint32_t near_bits = ORDER == 1 ? 0x3C800000u : 0x3B000000u;         // 2^-6 / 2^-9 as float bits
-  template <int ORDER>
-  __device__ static __forceinline__ float weight_far(float r2, float mj, float eps = FLT_EPSILON) {
-    const float y  = __builtin_amdgcn_rsqf(r2);
-    const float y3 = (y * y) * y;
-    const float my = mj * y3;
-    if constexpr (ORDER == 0) return my;             // no eps term at all (r2 >= 4 for the whole batch)
-    const float q = eps * y3;
-    if constexpr (ORDER == 1) return __builtin_fmaf(my, -q, my);
-    return __builtin_fmaf(my, __builtin_fmaf(q, q, -q), my);
-  }
+  // Sparse systems (ap_far_mode): a pair at r2 >= 4 takes m y^3 — eps u <= 2^-26 there, an eighth of an ulp.  Measured with it
+  // and not kept (round 3, profiles/r03/f32_pair_forms.txt): the reciprocal-free series m u (1 - q + q^2) for every far pair —
+  // v_rcp_f32 costs ~3 FMA slots on this chip, the series 2-3 FMAs plus a near check: slower wherever the check is taken.
+  static constexpr uint32_t far_bits = 0x40800000u;  // 4.0f
 };
 
 // LDS source record: (x[0..D-1], m) padded to a power-of-two size so one or two ds_read_b128 fetch it.
@@ -267,24 +239,6 @@ __device__ __forceinline__ void pair_accumulate(T (&acc)[D], const T (&xi)[D], c
 #pragma unroll
   for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
   T w = pair_math<T>::weight(r2, s.m);
-#pragma unroll
-  for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
-}
-
-// Same, for lanes selected by `take`; the others add w = 0, i.e. exactly nothing (d is finite).  Used by the
-// wave-cooperative traversal under a WAVE-UNIFORM branch: predicating the weight (2 v_cndmask) instead of the
-// control flow keeps the accumulators in place — with a divergent `if` hipcc copies all of them at both ends of
-// every loop iteration.
-template <typename T, int D>
-__device__ __forceinline__ void pair_accumulate_if(bool take, T (&acc)[D], const T (&xi)[D], const src_rec<T, D>& s) {
-  T d[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) d[k] = s.p[k] - xi[k];
-  T r2 = pair_math<T>::tiny;
-#pragma unroll
-  for (int k = 0; k < D; ++k) r2 = __builtin_elementwise_fma(d[k], d[k], r2);
-  T w = pair_math<T>::weight(r2, s.m);
-  w   = take ? w : T(0);
 #pragma unroll
   for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w, d[k], acc[k]);
 }
@@ -312,43 +266,6 @@ __device__ __forceinline__ void pair_accumulate_multi(T (&acc)[D], const T (&xi)
   for (int b = 0; b < NB; ++b) {
 #pragma unroll
     for (int k = 0; k < D; ++k) acc[k] = __builtin_elementwise_fma(w[b], d[b][k], acc[k]);
-  }
-}
-
-// K2 in f32 with a reciprocal-free weight (NBODY_F32_PAIR != 0): G sources against one target, the smallest r2 of the G pairs
-// tracked, one wave-uniform branch into the guarded form per G pairs; each lane keeps per pair what its own r2 asks for.
-#ifndef NBODY_K2_TIER_G
-  #define NBODY_K2_TIER_G 4
-#endif
-template <int D, int G>
-__device__ __forceinline__ void pair_accumulate_tier(float (&acc)[D], const float (&xi)[D], const src_rec<float, D>* s) {
-  constexpr int ORDER = (NBODY_F32_PAIR & 3) ? (NBODY_F32_PAIR & 3) : 2;
-  float d[G][D], r2[G], w[G];
-  uint32_t lowest = 0xffffffffu;
-#pragma unroll
-  for (int b = 0; b < G; ++b) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) d[b][k] = s[b].p[k] - xi[k];
-    float q = pair_math<float>::tiny;
-#pragma unroll
-    for (int k = 0; k < D; ++k) q = __builtin_fmaf(d[b][k], d[b][k], q);
-    r2[b]               = q;
-    const uint32_t bits = __builtin_bit_cast(uint32_t, q);
-    lowest              = bits < lowest ? bits : lowest;
-  }
-#pragma unroll
-  for (int b = 0; b < G; ++b) w[b] = pair_math<float>::template weight_far<ORDER>(r2[b], s[b].m);
-  if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<float>::template near_bits<ORDER>) != 0ull, 0)) {
-#pragma unroll
-    for (int b = 0; b < G; ++b) {
-      const float wn = pair_math<float>::weight(r2[b], s[b].m);
-      w[b]           = __builtin_bit_cast(uint32_t, r2[b]) < pair_math<float>::template near_bits<ORDER> ? wn : w[b];
-    }
-  }
-#pragma unroll
-  for (int b = 0; b < G; ++b) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) acc[k] = __builtin_fmaf(w[b], d[b][k], acc[k]);
   }
 }
 
@@ -413,7 +330,7 @@ struct pair_consts<double> {
 template <typename T, int D, int R, int U, bool ffar>
 __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], const src_rec<T, D> (&s)[U],
                                            const pair_consts<T>& pc) {
-  if constexpr (sizeof(T) == 4 && (NBODY_F32_PAIR & 3) == 0) {
+  if constexpr (sizeof(T) == 4) {
     if constexpr (!ffar) {
 #pragma unroll
       for (int u = 0; u < U; ++u)
@@ -462,54 +379,6 @@ __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], 
 #pragma unroll
           for (int k = 0; k < D; ++k) acc[r][k] = __builtin_elementwise_fma(w[u][r], d[u][r][k], acc[r][k]);
     }
-  } else if constexpr (sizeof(T) == 4) {
-    constexpr int ORDER  = NBODY_F32_PAIR & 3;
-    constexpr bool FFAST = (NBODY_F32_PAIR & 4) != 0;
-    T d[U][R][D], r2[U][R], w[U][R];
-    uint32_t lowest = 0xffffffffu;
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int r = 0; r < R; ++r) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) d[u][r][k] = s[u].p[k] - xi[r][k];
-        T q = pair_math<T>::tiny;
-#pragma unroll
-        for (int k = 0; k < D; ++k) q = __builtin_elementwise_fma(d[u][r][k], d[u][r][k], q);
-        r2[u][r]            = q;
-        const uint32_t bits = __builtin_bit_cast(uint32_t, q);
-        lowest              = bits < lowest ? bits : lowest;
-      }
-    if (FFAST && __builtin_amdgcn_ballot_w64(lowest < pair_math<T>::far_bits) == 0ull) {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) w[u][r] = pair_math<T>::template weight_far<0>(r2[u][r], s[u].m);
-    } else {
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-          T eps = FLT_EPSILON;
-          if constexpr (FFAST) eps = __builtin_bit_cast(uint32_t, r2[u][r]) < pair_math<T>::far_bits ? FLT_EPSILON : T(0);
-          w[u][r] = pair_math<T>::template weight_far<ORDER>(r2[u][r], s[u].m, eps);
-        }
-      if (__builtin_expect(__builtin_amdgcn_ballot_w64(lowest < pair_math<T>::template near_bits<ORDER>) != 0ull, 0)) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const T wn = pair_math<T>::weight(r2[u][r], s[u].m);
-            w[u][r]    = __builtin_bit_cast(uint32_t, r2[u][r]) < pair_math<T>::template near_bits<ORDER> ? wn : w[u][r];
-          }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int k = 0; k < D; ++k) acc[r][k] = __builtin_elementwise_fma(w[u][r], d[u][r][k], acc[r][k]);
   } else {
     T d[U][R][D], r2[U][R], w[U][R];
     uint32_t lowest = 0xffffffffu;
@@ -599,13 +468,16 @@ constexpr uint32_t kFarMinBodies = 32768;  // below this the rule is "dense" by 
 // number of such pairs per batch is 256 * (4/3 pi 8) / V (256 * 4 pi / A in 2D); the rule asks for < 0.05.  Real systems are
 // clumpier than their box (the galaxy: 6 % of the batches at V = 4e6) — the rule only has to tell a unit cube from a galaxy.
 template <int D>
+__host__ __device__ inline bool ap_far_rule(const unsigned long long* ext, double* volume = nullptr) {  // the rule itself (host: nbody_all_pairs_pair_rule)
+  double vol = 1.0;
+  for (int k = 0; k < D; ++k) vol *= ext_value(~ext[D + k]) - ext_value(ext[k]);
+  if (volume) *volume = vol;
+  return vol >= (D == 3 ? 1.7e5 : 6.4e4);
+}
+template <int D>
 __device__ __forceinline__ bool ap_far_mode(const unsigned long long* __restrict__ ext) {
   if (ext == nullptr) return false;
-  double vol = 1.0;
-#pragma unroll
-  for (int k = 0; k < D; ++k) vol *= ext_value(~ext[D + k]) - ext_value(ext[k]);
-  const bool far = vol >= (D == 3 ? 1.7e5 : 6.4e4);
-  return __builtin_amdgcn_readfirstlane(int(far)) != 0;
+  return __builtin_amdgcn_readfirstlane(int(ap_far_rule<D>(ext))) != 0;
 }
 
 // ---- scalar-stream helpers (K1's default form, the energies) ------------------------------------------------

@@ -314,33 +314,11 @@ __global__ void ot_build_init_kernel(uint32_t n, const T* __restrict__ m, const 
 // ~12 ns each on this chip whatever else the kernel does (one per wave made the widest level 402 us, 37k atomics).
 constexpr int kOBuild = 1024;
 
-// Grid-wide barrier of a kernel whose blocks are all resident (one block per CU at most: ot_grid_blocks).  Every wave reaches an
-// exit: a block that has waited kBarrierSpins polls (seconds; e.g. the GPU is shared and its peers never got a slot) raises
-// kFlagBarrier, which nbody_octree_info reports, and the kernel's level loop ends on every block at its next check.
-constexpr uint32_t kBarrierSpins = 4u << 20;
-__device__ __forceinline__ bool ot_grid_barrier(uint32_t* counter, uint32_t& epoch, uint32_t* flags) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();  // release: this block's writes of the level before the arrival
-    const uint32_t target = (epoch + 1u) * gridDim.x;
-    atomicAdd(counter, 1u);
-    uint32_t spins = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > kBarrierSpins) {
-        atomicOr(flags, kFlagBarrier);
-        break;
-      }
-    }
-    __threadfence();  // acquire: the other blocks' writes (invalidates this CU's vector L1)
-  }
-  ++epoch;
-  __syncthreads();
-  return (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kFlagBarrier) == 0u;
-}
-__device__ __forceinline__ uint32_t ot_count(const uint32_t* lvl_count, int level) {  // written by other blocks of this kernel
-  return __hip_atomic_load(lvl_count + level, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+#ifdef NBODY_EXPERIMENTS
+#define OT_FORMS_PART 1
+#include "experiments/octree_forms.inc"  // the grid barrier of build forms 2 and 4 (measured, not shipped)
+#undef OT_FORMS_PART
+#endif
 
 // One block's share of one level: cells [vblock * 1024 / 2^D, ...) of `count`.  `cells`, `lvl_count` and the tree are written by
 // other blocks during the all-level kernel, so nothing here is __restrict__ and the counters are read with agent-scope loads.
@@ -437,29 +415,6 @@ __global__ __launch_bounds__(kOBuild) void ot_build_level_kernel(int level, cons
   uint32_t base = 0;  // cells of the shallower levels = rank of this level's first cell
   for (int j = 0; j < level; ++j) base += lvl_count[j];
   ot_build_level_body<T, D>(level, blockIdx.x, count, base, skeys, sidx, m, x, tree, cells, lvl_count, flags, capacity, max_cells);
-}
-
-// All levels in ONE launch: the step loop of a small system is bound by its ~75 dependent launches (4.6 us each inside a
-// recorded step: half of the octree step at N = 10^5).  A grid of at most one 1024-thread block per CU walks the levels with a
-// grid barrier between them and stops at the first level without cells.
-template <typename T, int D>
-__global__ __launch_bounds__(kOBuild) void ot_build_all_levels_kernel(const uint64_t* __restrict__ skeys,
-                                                                      const uint32_t* __restrict__ sidx, const T* __restrict__ m,
-                                                                      const T* __restrict__ x, ot_tree<T, D> tree, ot_cell* cells,
-                                                                      uint32_t* lvl_count, uint32_t* flags, uint32_t capacity,
-                                                                      uint32_t max_cells, int first_level) {
-  constexpr uint32_t NCH = 1u << D;
-  uint32_t* counter = lvl_count + (kMaxLevels<D> + 3);
-  uint32_t epoch = 0, base = 0;
-  for (int j = 0; j < first_level; ++j) base += ot_count(lvl_count, j);  // levels built by earlier launches
-  for (int level = first_level; level < kMaxLevels<D>; ++level) {
-    const uint32_t count = ot_count(lvl_count, level);  // final: every block has passed the barrier behind level - 1
-    if (count == 0) break;                              // (the same value on every block: they leave together)
-    for (uint32_t vb = blockIdx.x; vb * (kOBuild / NCH) < count; vb += gridDim.x)
-      ot_build_level_body<T, D>(level, vb, count, base, skeys, sidx, m, x, tree, cells, lvl_count, flags, capacity, max_cells);
-    base += count;
-    if (!ot_grid_barrier(counter, epoch, flags)) break;
-  }
 }
 
 // ---- cells below the key depth ------------------------------------------------------------------------------------------
@@ -661,28 +616,11 @@ __global__ __launch_bounds__(kOB) void ot_multipole_level_kernel(int level, ot_t
   ot_multipole_cell<T, D>(tree, cells[base + k].node);
 }
 
-// All levels, deepest first, in ONE launch with a grid barrier between non-empty levels (see ot_build_all_levels_kernel).  The
-// cell lists and level counts are final here (the build is an earlier launch); only the tree's monopoles change.
-template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_multipole_all_levels_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
-                                                                      const uint32_t* __restrict__ lvl_count, uint32_t* counter,
-                                                                      uint32_t* flags, int lowest_level, uint32_t max_cells) {
-  uint32_t cnt[kMaxLevels<D>], total = 0;
-#pragma unroll
-  for (int l = 0; l < kMaxLevels<D>; ++l) {
-    cnt[l] = lvl_count[l];
-    total += cnt[l];
-  }
-  uint32_t epoch = 0, base = total;
-  for (int l = kMaxLevels<D> - 1; l >= lowest_level; --l) {
-    const uint32_t count = cnt[l];
-    if (count == 0) continue;
-    base -= count;
-    for (uint32_t k = blockIdx.x * kOB + threadIdx.x; k < count && base + k < max_cells; k += gridDim.x * kOB)
-      ot_multipole_cell<T, D>(tree, cells[base + k].node);
-    if (l > lowest_level && !ot_grid_barrier(counter, epoch, flags)) break;
-  }
-}
+#ifdef NBODY_EXPERIMENTS
+#define OT_FORMS_PART 2
+#include "experiments/octree_forms.inc"  // the all-level kernels of build forms 2 and 4
+#undef OT_FORMS_PART
+#endif
 
 // ---- one-pass build (nbody_octree_set_build 3 / auto) -----------------------------------------------------------------------
 // The per-level build above is a chain of dependent launches (a level's cell list is the product of the level before), and a
@@ -2374,7 +2312,11 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   // nbody_octree_info saw it (+ 2) — share ONE launch that walks them with a grid barrier and normally returns at once.  (All levels
   // behind grid barriers, nbody_octree_set_build(t, 2), is slower on this chip: an agent-scope barrier has to write back and
   // invalidate the per-XCD L2s and costs ~12 us, a dependent launch 4.6 us — N = 10^5: 0.87 against 0.55 ms per step.)
+#ifdef NBODY_EXPERIMENTS
   const int own = t->build == 2 ? 0 : (t->depth_hint < kMaxLevels<D> ? t->depth_hint : kMaxLevels<D>);
+#else
+  constexpr int own = kMaxLevels<D>;  // build form 1: every level its own launch
+#endif
   {
     uint64_t width = 1;  // a level has at most min(n/2, 2^(D*level)) cells to split
     for (int l = 0; l < own; ++l) {
@@ -2386,6 +2328,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
       if (width < (uint64_t(1) << 40)) width *= NCH;
     }
   }
+#ifdef NBODY_EXPERIMENTS
   if (own < kMaxLevels<D>) {  // at most one block per CU, and no more blocks than the widest level can use
     const uint64_t widest = uint64_t(n / 2 + 1) * NCH;
     uint32_t grid         = uint32_t((widest + kOBuild - 1) / kOBuild);
@@ -2395,6 +2338,7 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
                        t->max_cells, own);
     NB_HIP(hipGetLastError());
   }
+#endif
   // cells still holding >= 2 bodies at the key depth (none in a typical step: the kernel then returns at once)
   hipLaunchKernelGGL((ot_build_deep_kernel<T, D>), dim3(64), dim3(64), 0, st, t->idx[fin], t->idx[1 - fin],
                      static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<const T*>(t->root), tree, t->cells,
@@ -2432,6 +2376,7 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
     NB_HIP(hipGetLastError());
     return NBODY_OK;
   }
+#ifdef NBODY_EXPERIMENTS
   const int own = t->build == 2 ? 0 : (t->depth_hint < kMaxLevels<D> ? t->depth_hint : kMaxLevels<D>);
   if (own < kMaxLevels<D>) {  // the levels below `own`, deepest first, in one launch (see ot_insert_run)
     uint32_t grid = (t->n / 2 + 1 + kOB - 1) / kOB;
@@ -2440,6 +2385,9 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
                        t->lvl_count + (kMaxLevels<D> + 4), t->lvl_count + (kMaxLevels<D> + 2), own, t->max_cells);
     NB_HIP(hipGetLastError());
   }
+#else
+  constexpr int own = kMaxLevels<D>;
+#endif
   for (int l = own - 1; l >= 0; --l) {
     uint64_t width = 1;
     for (int j = 0; j < l && width < (uint64_t(1) << 40); ++j) width *= NCH;
@@ -2524,9 +2472,16 @@ extern "C" int nbody_octree_set_walk(nbody_octree* t, int mode) {
 
 extern "C" int nbody_octree_set_build(nbody_octree* t, int mode) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+#ifdef NBODY_EXPERIMENTS
   NB_ARG(mode >= 0 && mode <= 4,
          "build form must be 0 (auto), 1 (one launch per level), 2 (all levels in one launch), 3 (one pass over the sorted keys) or 4 "
          "(one launch per level the last tree used, one for the rest), got %d", mode);
+#else
+  NB_ARG(mode == 0 || mode == 1 || mode == 3, "build form must be 0 (auto), 1 (breadth-first, one launch per level) or 3 (one pass over the sorted keys), got %d%s",
+         mode, mode == 2 || mode == 4 ? " — that form exists only in the -DNBODY_EXPERIMENTS build (make experiments)" : "");
+#endif
+  if (mode != t->build) t->inserted = t->have_tree = false;  // the forms lay the cell list out differently: a tree inserted by one
+                                                             // is not the other's to finish (insert again after a change)
   t->build = mode;
   if (mode != 4) t->depth_hint = 64;  // 1: every level its own launch, whatever earlier trees looked like
   return NBODY_OK;
@@ -2642,7 +2597,8 @@ extern "C" void nbody_octree_destroy(nbody_octree* t) {
 
 extern "C" int nbody_octree_clear(nbody_octree* t, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
-  (void)stream;  // every node the build allocates is fully rewritten by it: nothing to reset but the phase flags
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_octree")) return r;
+  // every node the build allocates is fully rewritten by it: nothing to reset but the phase flags
   t->inserted  = false;
   t->have_tree = false;
   return NBODY_OK;
@@ -2676,6 +2632,7 @@ extern "C" int nbody_octree_insert(nbody_octree* t, const nbody_state* s, void* 
 
 extern "C" int nbody_octree_compute_tree(nbody_octree* t, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_octree")) return r;
   device_guard guard(t->device);
   if (!t->inserted) {
     set_error("nbody_octree_compute_tree before nbody_octree_insert");
@@ -2712,6 +2669,7 @@ extern "C" int nbody_octree_enable_counters(nbody_octree* t, int on) {
 
 extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* root_mass, void* stream) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_octree")) return r;
   device_guard guard(t->device);
   if (!t->inserted) {
     set_error("nbody_octree_info before nbody_octree_insert");
@@ -2763,6 +2721,7 @@ extern "C" int nbody_octree_info(nbody_octree* t, uint32_t* tree_size, void* roo
 extern "C" int nbody_octree_read_counters(nbody_octree* t, uint32_t* host_out, size_t bytes, void* stream) {
   NB_ARG(t != nullptr && host_out != nullptr, "NULL argument");
   NB_ARG(t->counters != nullptr, "counters were never enabled");
+  if (int r = check_same_device(t->device, as_stream(stream), "nbody_octree")) return r;
   device_guard guard(t->device);
   NB_ARG(bytes == sizeof(uint32_t) * 2 * size_t(t->n), "expected %zu bytes", sizeof(uint32_t) * 2 * size_t(t->n));
   NB_HIP(hipMemcpyAsync(host_out, t->counters, bytes, hipMemcpyDeviceToHost, as_stream(stream)));

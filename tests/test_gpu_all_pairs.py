@@ -575,17 +575,9 @@ def test_near_pairs_in_another_source_tile(nb, oracle, dtype, dim, extreme):
     else:
         # float: the oracle (like the reference's transform_reduce on a serial backend) adds 3.6e7 terms into ONE float
         # accumulator, which by itself drifts 3e-5 from the exact sum of the same terms (measured: -58563080 against
-        # -58564799.4); the kernel's tree-shaped sum does not.  The yardstick is therefore the same expression,
-        # m_i m_j / (|x_i - x_j| + eps(float)) over the float inputs, evaluated in float64.
-        x64, m64, eps32 = hs.x.astype(np.float64), hs.m.astype(np.float64), float(np.finfo(np.float32).eps)
-        pe64 = 0.0
-        for i0 in range(0, hs.n, 500):
-            d = x64[i0:i0 + 500, None, :] - x64[None, :, :]
-            term = m64[i0:i0 + 500, None] * m64[None, :] / (np.sqrt((d * d).sum(-1)) + eps32)
-            rows = np.arange(term.shape[0])
-            term[rows, i0 + rows] = 0.0
-            pe64 += term.sum()
-        pe64 *= -0.5 * hs.c
+        # -58564799.4); the kernel's tree-shaped sum does not.  The yardstick is therefore the oracle's own terms summed in
+        # double (oracle.calc_energies_wide, src/system.h:62-79), against which the oracle's float sum is held too.
+        _, pe64 = oracle.calc_energies_wide(ref)
         assert np.isfinite(pe) and abs(pe - pe64) <= 2e-6 * abs(pe64), (pe, pe64)
         assert abs(ope - pe64) <= 1e-4 * abs(pe64), (ope, pe64)
     dev.close()
@@ -625,7 +617,12 @@ def test_sparse_system_pair_rules_with_planted_pairs(nb, oracle, dim):
     planted = np.array(planted)
     hs.c, hs.dt = 1.0, 0.01
     dev = nb.DeviceSystem.from_host(hs)
-    assert "sparse" in nb.describe_all_pairs(dev.state()) or "far" in nb.describe_all_pairs(dev.state())
+    sparse, vol = nb.all_pairs_pair_rule(dev.state(), dev.stream)   # the rule in force is a property of the system's extent
+    assert sparse and vol >= (1.7e5 if dim == 3 else 6.4e4), (sparse, vol)
+    assert nb.all_pairs_pair_rule(dev.state(100, 5000), dev.stream) == (sparse, vol)   # ... the same for every shard window
+    dense = nb.DeviceSystem.from_host(nb.build_model(nb.F64, dim, "uniform", n))      # the unit cube: the dense rule
+    assert nb.all_pairs_pair_rule(dense.state(), dense.stream)[0] is False
+    dense.close()
     dev.all_pairs_force()
     dev.sync()
     a = dev.download().a.astype(np.float64)

@@ -102,7 +102,7 @@ def test_bvh_randomized_systems_bit_exact(nb, oracle):
         dtype, dim = int(rng.integers(0, 2)), int(rng.integers(2, 4))
         n = int(rng.integers(2, 3000))
         theta = float(rng.choice([0.0, 0.2, 0.5, 0.9, 1.4]))
-        modes = (1, 3, 4, 5, 2)  # 5 / 2: the hand-scheduled sweep
+        modes = (1, 5, 2, 0)  # per-lane walks; 5 / 2: the sweep (step program as ISA); 0: auto
         _phases(nb, oracle, dtype, dim, None, n, theta, counts=True, traversal=modes[case % len(modes)],
                 system=_random_system(nb, oracle, rng, dtype, dim, n))
 
@@ -114,8 +114,8 @@ def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
     for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0),
                               (3, "uniform", 4096, 3.0), (2, "galaxy", 64, 2.5)):
         res = []
-        # per-lane walks; compiler-scheduled sweep with 1 and with 2 bodies per lane; the sweep written as ISA
-        for mode in (1, 3, 4, 5):
+        # per-lane walks (the reference's loop and its product form of the opening test); the sweep (ISA, one-compare opening test)
+        for mode in (1, 5):
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.bvh.set_traversal(mode)
             dev.bvh.enable_counters(True)
@@ -169,7 +169,7 @@ def test_traversal_forms_fuzz(nb, oracle, dtype, dim):
         theta = float(rng.choice([0.0, 0.3, 0.7, 1.5]))
         ocnt = oracle.bvh_force(ref, tr, theta, want_counts=True)
         res = []
-        for mode in (1, 3, 5, 0, 6):
+        for mode in (1, 5, 0):
             dev = nb.DeviceSystem.from_host(hs)
             dev.bvh.set_traversal(mode)
             dev.bvh.enable_counters(mode != 6)   # (the row sweep has no counters)
@@ -366,7 +366,7 @@ def test_sweep_work_items_and_shard_windows(nb):
     t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
     t.enable_counters(True)
     res = {}
-    for mode, order in ((1, 0), (3, 0), (3, 1), (4, 0), (5, 0), (5, 1)):
+    for mode, order in ((1, 0), (5, 0), (5, 1), (0, 0)):
         t.set_traversal(mode)
         t.set_launch_order(order)
         t.compute_force(st, 0.5, dev.stream)
@@ -376,7 +376,7 @@ def test_sweep_work_items_and_shard_windows(nb):
     base = res[(1, 0)]
     for k, r in res.items():
         assert np.array_equal(r[0], base[0]) and np.array_equal(r[1], base[1]), k
-    for mode in (3, 5):
+    for mode in (5,):
         t.set_traversal(mode)
         for first, count in ((0, 70000), (70000, 65539), (135539, n - 135539)):
             w = dev.state(first, count)
@@ -398,7 +398,7 @@ def test_traversal_terminates_on_nan_and_inf_positions():
         nb = load_package()
         for bad in (np.nan, np.inf, -np.inf):
             for dtype in (1, 0):
-                for mode in (1, 3, 5):
+                for mode in (1, 5):
                     hs = nb.build_model(dtype, 3, "galaxy", 5000)
                     hs.x[17, 0] = bad; hs.x[4000, 2] = bad; hs.x[4999] = bad
                     dev = nb.DeviceSystem.from_host(hs)
@@ -435,7 +435,7 @@ def test_key_ties_match_the_reference_as_multisets(nb, oracle, golden_bvh_ties):
         keys = t.read(0, dev.stream)
         assert len(np.unique(keys)) <= case["n"] - 3, name       # the ties are real on the device too
         dev.close()
-        for mode in (1, 3, 5):
+        for mode in (1, 5):
             dev = fresh()
             dev.bvh.set_traversal(mode)
             nb.run(dev, "bvh", 12, 0.0)
@@ -447,26 +447,56 @@ def test_key_ties_match_the_reference_as_multisets(nb, oracle, golden_bvh_ties):
         dev.close()
 
 
-@pytest.mark.parametrize("dtype", [1, 0])
-def test_row_sweep_form_is_bitwise_equal(nb, dtype):
-    """Traversal mode 6 — four independent 16-lane row sweeps per wave, the experiment VERDICT r2 asked to be built and timed
-    (profiles/r03/k9_row_sweep.txt: 16.1 ms against 8.8 for the compiler-scheduled wave sweep at config 4) — makes every body perform
-    the same tests in the same order as every other form: accelerations bitwise equal, whole system and a shard window."""
-    n = 150001
-    dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
-    st, t = dev.state(), dev.bvh
-    t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
-    out = {}
-    for mode in (1, 6):
-        t.set_traversal(mode)
-        t.compute_force(st, 0.5, dev.stream)
-        dev.sync()
-        out[mode] = dev.download().a.copy()
-        t.compute_force(dev.state(40000, 70001), 0.5, dev.stream)
-        dev.sync()
-        assert np.array_equal(dev.download().a[40000:110001], out[mode][40000:110001]), mode
-    assert np.array_equal(out[1], out[6])
-    t.enable_counters(True)
-    with pytest.raises(nb.NbodyError, match="no counters"):
-        t.compute_force(st, 0.5, dev.stream)
+def test_unshipped_forms_are_refused(nb):
+    """The measured forms that lost (compiler-scheduled sweep, two bodies per lane, row sweeps) live in the -DNBODY_EXPERIMENTS
+    build only; the shipped library refuses them by name."""
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 5000))
+    for mode in (3, 4, 6):
+        with pytest.raises(nb.NbodyError, match="NBODY_EXPERIMENTS"):
+            dev.bvh.set_traversal(mode)
+    for mode in (2, 4):
+        with pytest.raises(nb.NbodyError, match="NBODY_EXPERIMENTS"):
+            dev.octree.set_build(mode)
     dev.close()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_experiment_forms_are_bitwise_equal(dtype):
+    """With libnbody_hip_exp.so (make experiments; the driver's build() makes it): traversal modes 3, 4 and 6 and octree build forms
+    2 and 4 perform the same tests in the same order as the shipped forms.  A child process, because a process loads one library."""
+    import subprocess, sys, os, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "stdpar-nbody_amd", "libnbody_hip_exp.so")
+    if not os.path.exists(lib):
+        pytest.skip("libnbody_hip_exp.so not built (make -C stdpar-nbody_amd experiments)")
+    code = textwrap.dedent(f"""
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        from conftest import load_package
+        nb = load_package()
+        nb.LIB_PATH = {lib!r}
+        n = 60001
+        dev = nb.DeviceSystem.from_host(nb.build_model({dtype}, 3, "galaxy", n))
+        st, t = dev.state(), dev.bvh
+        t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
+        out = {{}}
+        for mode in (1, 5, 3, 4, 6):
+            t.set_traversal(mode)
+            t.compute_force(st, 0.5, dev.stream); dev.sync()
+            out[mode] = dev.download().a.copy()
+        assert all(np.array_equal(out[1], out[m]) for m in out), "bvh traversal forms"
+        res = []
+        for form in (3, 1, 2, 4):
+            d2 = nb.DeviceSystem.from_host(nb.build_model({dtype}, 3, "galaxy", n))
+            d2.octree.set_build(form)
+            d2.octree.enable_counters(True)
+            for _ in range(2):
+                d2.octree_force(0.5); d2.sync()
+                info = d2.octree.info(d2.stream)
+            res.append((info, d2.octree.read_counters(d2.stream).copy(), d2.download().a.copy()))
+            d2.close()
+        assert all(r[0] == res[0][0] and np.array_equal(r[1], res[0][1]) and np.array_equal(r[2], res[0][2]) for r in res), "octree build forms"
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-1500:]

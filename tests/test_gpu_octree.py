@@ -69,7 +69,7 @@ ISA_WALKS = [(1, 3), (0, 3), (0, 2), (1, 2)]
 
 
 @pytest.mark.parametrize("dtype,dim", ISA_WALKS)
-def test_octree_walk_forms_stress(nb, dtype, dim):
+def test_octree_walk_forms_stress(nb, oracle, dtype, dim):
     """Hand-written ISA is only as good as its hazards: repeated walks of one tree of 200 000 uniformly random bodies per theta,
     by BOTH instantiations of the ISA round (with and without the counters: different register allocations around the same
     text), must reproduce the compiler-scheduled kernel's counters and accelerations bit for bit EVERY time.  (Round 3: a
@@ -89,6 +89,12 @@ def test_octree_walk_forms_stress(nb, dtype, dim):
         t.compute_force(st, theta, dev.stream)
         dev.sync()
         cnt, acc = t.read_counters(dev.stream).copy(), dev.download().a.copy()
+        ref = oracle.State(dtype, dim, n)   # the walk the forms must reproduce is the reference's, not merely each other's
+        ref.m[:], ref.x[:], ref.c, ref.dt = hs.m, hs.x, hs.c, hs.dt
+        ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+        assert t.info(dev.stream) == (osize, omass)
+        assert np.array_equal(cnt, ocnt), (theta, "visit counters vs the oracle")
+        assert maxrel(acc, ref.a) <= FORCE_TOL[dtype], theta
         t.set_walk(2)
         for rep in range(4):
             t.compute_force(st, theta, dev.stream)
@@ -358,7 +364,7 @@ def test_octree_build_forms_over_many_steps(nb, dtype):
 
 
 @pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2), (0, 2)])
-def test_octree_build_forms_fuzz(nb, dtype, dim):
+def test_octree_build_forms_fuzz(nb, oracle, dtype, dim):
     """The one-pass build against the breadth-first one on geometry that random clouds do not produce: bodies exactly on cell
     boundaries (grid-aligned coordinates: `pos > divide` is false on the boundary), on a line, on a plane, in tight clusters with
     a far escaper, with many equal coordinates, in sizes around the kernels' block sizes.  Tree size, root monopole, counters and
@@ -396,7 +402,7 @@ def test_octree_build_forms_fuzz(nb, dtype, dim):
         hs.x[:] = x.astype(t)
         hs.c, hs.dt = 1.0, 1e-3
         res = []
-        for form in (1, 3, 4, 2):
+        for form in (1, 3):
             dev = nb.DeviceSystem.from_host(hs)
             dev.octree.set_build(form)
             dev.octree.enable_counters(True)
@@ -412,6 +418,18 @@ def test_octree_build_forms_fuzz(nb, dtype, dim):
             assert res[0][0] == r[0], (case, n, kind, res[0][0], r[0])
             if res[0][0][0] != "refused":
                 assert np.array_equal(res[0][1], r[1]) and np.array_equal(res[0][2], r[2]), (case, n, kind)
+        # ... and against the reference's own insertion (src/octree.h:114-180, restated by the oracle): the same tree size, root
+        # monopole and per-body counters for every tree the product accepts, a pool overflow for every one it refuses
+        ref = oracle.State(dtype, dim, n)
+        ref.m[:], ref.x[:], ref.c, ref.dt = hs.m, hs.x, hs.c, hs.dt
+        if res[0][0][0] == "refused":
+            with pytest.raises(RuntimeError):
+                oracle.octree_step_force(ref, 0.4)
+        else:
+            ocnt, osize, omass = oracle.octree_step_force(ref, 0.4, want_counts=True)
+            assert res[0][0] == (osize, omass), (case, n, kind, res[0][0], (osize, omass))
+            assert np.array_equal(res[0][1], ocnt), (case, n, kind, "visit counters vs the oracle")
+            assert maxrel(res[0][2], ref.a) <= FORCE_TOL[dtype], (case, n, kind)
         if res[0][0][0] != "refused":
             walks = []
             for walk in (1, 2):   # the compiler-scheduled walk and the visit round written as ISA, on the same degenerate tree
@@ -426,7 +444,7 @@ def test_octree_build_forms_fuzz(nb, dtype, dim):
             assert np.array_equal(walks[0][1], res[0][2]), (case, n, kind)
 
 
-@pytest.mark.parametrize("form", [3, 1, 4, 2])
+@pytest.mark.parametrize("form", [3, 1])
 def test_octree_node_pool_exhausted_above_the_key_depth(nb, oracle, form):
     """Ten pairs 2^-18 of the root side apart make ten chains of ~17 nested cells: 170 sibling groups against the 125 the
     reference's pool holds for 20 bodies (System::max_tree_node_size = max(1000, 8 n) nodes, src/system.h:30).  The oracle's
@@ -634,21 +652,19 @@ def test_octree_walk_stack_full_and_step_budget_exits(nb, oracle, form):
 
 @pytest.mark.parametrize("dtype,dim", [(1, 3), (0, 3), (1, 2), (0, 2)])
 def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
-    """The ways to build the tree from the sorted keys: breadth-first with one launch per level (1), with one launch per level the
-    previous tree used (+ 2) and ONE launch that walks all deeper levels behind a grid barrier (4 — the second build of each
-    case below runs with the depth the first one reported), with every level behind the grid barrier (2); and in one pass from
-    the common key prefixes of neighbouring bodies (3 = auto, 0), which numbers the sibling groups in pre-order instead of
+    """The two shipped ways to build the tree from the sorted keys: breadth-first with one launch per level (1), and in one pass
+    from the common key prefixes of neighbouring bodies (3 = auto, 0), which numbers the sibling groups in pre-order instead of
     breadth-first.  Same tree size, same root monopole, same per-body counters and accelerations, bit for bit — also with cells
-    below the key depth, with a 60-level chain of nested cells (the deeper levels are NOT empty for a hint taken from a shallow
-    tree; in the one-pass build one position starts 20 cells), for two and three bodies, and for sizes around the 1024-position
-    blocks of the prefix sum."""
+    below the key depth, with a 60-level chain of nested cells (in the one-pass build one position starts 20 cells), for two and
+    three bodies, and for sizes around the 1024-position blocks of the prefix sum.  (The grid-barrier forms 2 and 4 live in the
+    experiments build: tests/test_gpu_bvh.py::test_experiment_forms_are_bitwise_equal.)"""
     cases = [("galaxy", 100000), ("uniform", 30011), ("galaxy", 2), ("uniform", 1), ("uniform", 3), ("uniform", 1023), ("uniform", 1024),
              ("uniform", 1025), ("galaxy", 2049), ("galaxy", 300000)]   # 300 000: the multipole pass takes its second round
     if dim == 3:
         cases.append(("plummer", 5000))
     for wl, n in cases:
         res = []
-        for form in (2, 1, 4, 3, 0):
+        for form in (1, 3, 0):
             hs = nb.build_model(dtype, dim, wl, n)
             if wl == "uniform" and n > 1000:  # pairs far below the key resolution and an escaper that inflates the root cube
                 hs.x[1] = hs.x[0] + (1e-9 if dtype == 1 else 1e-6)
@@ -656,7 +672,7 @@ def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
             dev = nb.DeviceSystem.from_host(hs)
             dev.octree.set_build(form)
             dev.octree.enable_counters(True)
-            for _ in range(2):   # twice: the barrier counters are reset by every build; auto then knows the depth
+            for _ in range(2):   # twice: nothing is cleared between builds
                 dev.octree_force(0.5)
                 dev.sync()
                 size, mass = dev.octree.info(dev.stream)
@@ -667,8 +683,8 @@ def test_octree_build_forms_are_bitwise_equal(nb, dtype, dim):
             assert np.array_equal(res[0][2], r[2]) and np.array_equal(res[0][3], r[3]), (wl, n)
     if dtype == 1 and dim == 3:
         outs = []
-        for form in (2, 1, 4, 3, 0):
-            # 4: the hint comes from a shallow tree first (a galaxy of as many bodies), then the chain is built with it
+        for form in (1, 3, 0):
+            # a shallow tree first (a galaxy of as many bodies), then the chain in the same buffers
             shallow = nb.build_model(1, 3, "galaxy", _deep_chain(nb, 60).n)
             dev = nb.DeviceSystem.from_host(shallow)
             dev.octree.set_build(form)

@@ -11,7 +11,7 @@ dtype = nb.F32 if (len(sys.argv) > 2 and sys.argv[2] == "float") else nb.F64
 dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
 st, t = dev.state(), dev.bvh
 t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream); dev.sync()
-for mode in (1, 3, 5):
+for mode in ((1, 3, 5, 6) if "exp" in sys.argv[1:] else (1, 5)):
     t.set_traversal(mode)
     t.compute_force(st, 0.5, dev.stream); dev.sync()
     acc = dev.download().a.copy()

@@ -27,7 +27,7 @@ def per_step(dev, step, steps=200):
 
 for n in (10000, 100000, 1000000):
     row = []
-    for form in (1, 4, 2, 3):
+    for form in (1, 3):
         dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
         dev.octree.set_build(form)
         dev.octree_force(0.5); dev.octree.info(dev.stream)   # build 4: the tree's depth is known from here on

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One GPU-box session that produces everything kept under profiles/<tag>/: the bench line, its rocprofv3 summaries (stamped),
 # the per-config timings, the reference-shaped benchmark logs + scraped tables, and PMC passes of K2 and K9.
-# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r03
-TAG=${1:-r03}
+# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r04
+TAG=${1:-r04}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -4,7 +4,7 @@
 # profiles/<tag>/ that bench.py accepts as evidence (same kernel description string, same K1 source hash).
 # Usage (on the GPU box, from the repo root): bash tools/profile_bench.sh <tag>
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/prof_$TAG

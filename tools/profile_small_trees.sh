@@ -2,7 +2,7 @@
 # (octree: the default one-pass build; bvh), summarised per step into gpurun_out/<tag>/small_trees_kernel_stats.txt
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r03}
+O=$R/gpurun_out/${1:-r04}
 mkdir -p $O
 S=210
 : > $O/small_trees_kernel_stats.txt

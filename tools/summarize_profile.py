@@ -73,6 +73,17 @@ def main():
         out["kernel"] = line["roofline"]["kernel"]
     out["kernel_name_in_profile"] = name
     out["source_sha"] = source_sha()
+    # what the profile says by itself: the clock the box sustained during the counted dispatch and the kernel's rate at that clock
+    if out.get("GRBM_GUI_ACTIVE") and out.get("duration_ns_pmc_sq") and out.get("n"):
+        cycles = out["GRBM_GUI_ACTIVE"] / 8.0  # summed over the 8 XCDs
+        secs = out["duration_ns_pmc_sq"] * 1e-9
+        flops = 20.0 * out["n"] * (out["n"] - 1)
+        out["effective_clock_ghz"] = cycles / secs / 1e9
+        out["tflops_in_pmc_pass"] = flops / secs / 1e12
+        out["frac_of_fp64_peak_at_2p4ghz"] = out["tflops_in_pmc_pass"] / 78.6
+        out["frac_of_fp64_peak_at_measured_clock"] = out["tflops_in_pmc_pass"] / (78.6 * out["effective_clock_ghz"] / 2.4)
+    if line and line.get("gpu_telemetry"):
+        out["sclk_mhz_mean_traced_run"] = line["gpu_telemetry"].get("sclk_mhz_mean")
     out["_note"] = ("per dispatch of the dominant kernel, rocprofv3 --pmc in separate passes (tools/profile_bench.sh); "
                     "duration_ns_* = that dispatch's duration in the pass; FETCH_SIZE / WRITE_SIZE in KB as reported "
                     "(bench.py doubles FETCH_SIZE for gfx950 per MI355X_MICROARCH.md)")

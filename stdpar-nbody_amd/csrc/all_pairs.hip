@@ -6,7 +6,7 @@
 //   * sources are packed (x, m) records visited in tiles of 512; every tile is cut into JS slices, one per wave of the
 //     block that shares a target group, and the tile sequence into source chunks over grid.y — both from sz alone, so a
 //     shard window (N/8 targets on one GPU) sums exactly as the whole system does and still fills the chip;
-//   * slice partials are combined through LDS in wave order, chunk sums by combine_chunks_kernel in chunk order:
+//   * slice partials are combined through LDS in wave order, chunk sums added in chunk order into `a` by the chunks' blocks in turn:
 //     deterministic, and independent of how bodies are sharded over GPUs.
 //   Two ways of bringing a source record to the 64 lanes that all need the same one (bitwise the same result):
 //   - LDS tiles (all_pairs_force_kernel): tiles staged in LDS by all 256 lanes with a register prefetch of the
@@ -241,23 +241,29 @@ __global__ __launch_bounds__(kBlock) void extent_kernel(const T* __restrict__ x,
 template <int JS>
 constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the scalar-stream form
 
-// One chunk of one target block, start to finish — the block shape of rounds 2-3, kept for single precision: the f32 source loop
-// is the tightest in the library (12 full-rate instructions and two transcendentals per pair) and anything around it shows: inside
-// the chunk-walking body below it runs 3-5 % slower although its instructions are the same (same instruction counts, same
-// scalar-cache hits, more cycles; VGPR banks do not matter: tools/microbench/vgpr_banks.hip), and the second copy of the loop that
-// the sparse rule needs costs the dense copy 5 % (N = 262 144: 20.85 -> 21.95 ms) while the galaxy gains 6 % (20.85 -> 19.3-19.7).
-// Measured alternatives, all worse for the dense cube (profiles/r04/ab_k1_f32_bodies*.txt): one kernel per rule, both launched, the
-// idle one's blocks returning at once (+ 7 %: 65 536 blocks dispatch at 22 ns each whatever they do); persistent blocks striding
-// over the chunks (+ 12 %).  chunk_sums == nullptr: the only chunk, `a` is written here.
+// Scalar-stream form.  grid = (target blocks, source chunks): block (b, y) sums chunk y's tiles for target block b — its JS slices'
+// sums added in slice order through LDS — and adds that sum s_y to the target's running total IN CHUNK ORDER:
+//     a = c * (((s_0 + s_1) + s_2) + ...),
+// the total living in `a` itself.  Block (b, y) waits until turn[b] == y (block (b, y - 1) has added its sum), adds, and passes the
+// turn on; the last chunk applies c.  No chunk-sum scratch (403 MB at N = 2^20 until round 3) and no combine launch.  Progress: a
+// block waits only for blocks of smaller linear index, which the dispatcher started earlier (workgroups are dealt to the XCDs
+// round-robin and started in order on each), so the unfinished block of smallest index is always running and never waits; in
+// practice nobody waits at all — block (b, y - 1) finished a whole round of blocks earlier.  A wait that outlasts kTurnSpins polls
+// (seconds) gives up and poisons its targets with NaN rather than hang the queue.  The running total is read and written with
+// agent-scope accesses (it changes hands between CUs and XCDs); what fixes the ROUNDING is unchanged from rounds 2-3, so every shard
+// window still sums exactly as the whole system does.
+constexpr uint32_t kTurnSpins = 1u << 26;
 template <typename T, int D, int R, int JS>
-__device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restrict__ packed, const T* __restrict__ x, T* __restrict__ a, T c,
-                                                  uint32_t sz, uint32_t first, uint32_t count, uint32_t tiles_per_chunk, uint32_t tblock,
-                                                  uint32_t chunk, uint32_t tail_first, T* __restrict__ chunk_sums,
-                                                  const unsigned long long* __restrict__ ext, T* partial) {
+__global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
+                                                                                   const T* __restrict__ x, T* a, T c, uint32_t sz,
+                                                                                   uint32_t first, uint32_t count,
+                                                                                   uint32_t tiles_per_chunk, uint32_t* turn,
+                                                                                   const unsigned long long* __restrict__ ext) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kSgprWaves<JS> / JS;
   constexpr int TB  = TG * 64 * R;
   constexpr int SUB = kTileJ / JS;
+  __shared__ T partial[(JS > 1) ? (JS - 1) * TG * 64 * R * D : 1];
   const int lane   = threadIdx.x & 63;
   const int wave   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tgroup = wave / JS;
@@ -266,7 +272,7 @@ __device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restric
   uint32_t ti[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
-    uint32_t local = tblock * TB + tgroup * (64 * R) + r * 64 + lane;
+    uint32_t local = blockIdx.x * TB + tgroup * (64 * R) + r * 64 + lane;
     ti[r]          = local;
     uint64_t i     = uint64_t(first) + (local < count ? local : 0u);
 #pragma unroll
@@ -275,18 +281,22 @@ __device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restric
       acc[r][k] = T(0);
     }
   }
+  // source chunk of this block (grid.y): tiles [t0, t1) of the padded source set; one chunk = everything when grid.y == 1
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
-  const uint32_t t0     = chunk * tiles_per_chunk;
+  const uint32_t t0     = blockIdx.y * tiles_per_chunk;
   const uint32_t t1     = min(ntiles, t0 + tiles_per_chunk);
   const pair_consts<T> pc;
   const bool ffar       = ap_far_mode<D>(ext);
-  const uint32_t nsteps = (t1 - t0) * SUB;
-  constexpr int U = 64 / int(sizeof(rec_t));
+  const uint32_t nsteps = (t1 - t0) * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
+  constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
   struct batch_t {
     rec_t r[U];
   };
   auto batch = [&](uint32_t k) { return packed + (uint64_t(t0 + k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
-  auto run = [&](auto ff) {
+  // Two SGPR buffers, each requested (s_load_dwordx16) one compute phase before it is consumed.  Written with inline
+  // asm: hipcc folds a loop-carried load from read-only memory back into a load at the loop top and waits for it there.
+  // SMEM returns out of order, so the only usable wait is lgkmcnt(0): wait for X, request Y, consume X.
+  auto run = [&](auto ff) {  // the source stream, once per pair rule (pair_batch)
     constexpr bool FF = decltype(ff)::value;
     sgpr16 A = sload16(batch(0), xi[0][0]), B;
     for (uint32_t k = 0; k < nsteps; k += 2 * U) {
@@ -297,15 +307,15 @@ __device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restric
         pair_batch<T, D, R, U, FF>(acc, xi, ba.r, pc);
       }
       swait(B, acc[0][0]);
-      A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);
+      A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
       {
         const batch_t bb = __builtin_bit_cast(batch_t, B);
         pair_batch<T, D, R, U, FF>(acc, xi, bb.r, pc);
       }
     }
-    swait(A, acc[0][0]);
+    swait(A, acc[0][0]);  // nothing in flight when the wave goes on
   };
-  if (ffar) run(std::true_type{});
+  if (ffar) run(std::true_type{});  // two copies of the loop: inside ONE loop hipcc hoists the rules' common head above the branch
   else run(std::false_type{});
   if constexpr (JS > 1) {
     if (jpart > 0) {
@@ -324,186 +334,64 @@ __device__ __forceinline__ void sgpr_single_chunk(const src_rec<T, D>* __restric
           for (int k = 0; k < D; ++k) acc[r][k] += partial[((((p - 1) * TG + tgroup) * R + r) * D + k) * 64 + lane];
     }
   }
-  if (jpart == 0) {
-    T* out        = chunk_sums ? chunk_sums + (uint64_t(chunk) * (count - tail_first) - tail_first) * D : a;
-    const T scale = chunk_sums ? T(1) : c;
+  if (jpart != 0) return;
+  const uint32_t y = blockIdx.y, last = gridDim.y - 1u;
+  bool poisoned = false;
+  if (y > 0) {  // my turn?  (one word per (target block, target group); wave-uniform address: every lane reads the same value)
+    uint32_t spins = 0;
+    while (__hip_atomic_load(turn + blockIdx.x * TG + tgroup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != y) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > kTurnSpins) {
+        poisoned = true;
+        break;
+      }
+    }
+  }
+  // The total's R * D * 64 scalars of this target group are contiguous in `a`: through LDS (the slices' partials are spent) every
+  // lane takes scalars e = q * 64 + lane, so each access is one full-width coalesced instruction — per component the lanes would
+  // touch every line three times (measured: 3.2 GB of traffic per launch at N = 2^20 instead of 1.3).
+  const uint32_t gbase = blockIdx.x * TB + tgroup * (64 * R);  // first target of the group
+  if constexpr (JS > 1) {
+    T* stage = partial + size_t(tgroup) * R * D * 64;  // [(jpart - 1 = 0) * TG + tgroup] block of the partials: read above, free now
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) stage[(r * 64 + lane) * D + k] = acc[r][k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < R * D; ++q) {
+      const uint32_t e = uint32_t(q) * 64u + uint32_t(lane);
+      if (gbase + e / D < count) {
+        T* slot = a + uint64_t(gbase) * D + e;
+        T t     = stage[e];
+        if (y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;  // ((s_0 + s_1) + ...) + s_y
+        if (y == last) t = c * t;
+        if (poisoned) t = __builtin_nan("");
+        __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       if (ti[r] < count) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) out[uint64_t(ti[r]) * D + k] = scale * acc[r][k];
-      }
-    }
-  }
-}
-
-// Source chunks are a ROUNDING rule, not a launch shape: a target's result is c * (((s_0 + s_1) + s_2) + ...) with s_y the sum
-// over chunk y's tiles (its JS slice sums added in slice order).  A block either walks ALL chunks of its target block in order —
-// fresh accumulators per chunk, the slice combine per chunk, the running total in LDS — and writes `a` itself (no scratch, no
-// second kernel), or computes ONE s_y and stores it for combine_chunks_kernel.  Bitwise the same result either way; which
-// target blocks take which form is the launch plan's business (sgpr_launch_shape).
-// (one target per lane: 8 waves per SIMD, i.e. at most 64 VGPRs — hipcc's own allocation of the f64 3D instance is 66)
-// (one target per lane: 8 waves per SIMD, i.e. at most 64 VGPRs)
-template <typename T, int D, int R, int JS>
-__global__ __launch_bounds__(64 * kSgprWaves<JS>) __attribute__((amdgpu_waves_per_eu(R == 1 ? 8 : 1)))
-void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
-                                                                                   const T* __restrict__ x, T* __restrict__ a, T c,
-                                 uint32_t sz, uint32_t first, uint32_t count, uint32_t tiles_per_chunk, uint32_t nchunks,
-                                 uint32_t long_blocks, uint32_t tail_blocks, T* __restrict__ chunk_sums,
-                                 const unsigned long long* __restrict__ ext) {
-  using rec_t = src_rec<T, D>;
-  constexpr int TG  = kSgprWaves<JS> / JS;
-  constexpr int TB  = TG * 64 * R;
-  constexpr int SUB = kTileJ / JS;
-  __shared__ T partial[(JS > 1) ? (JS - 1) * TG * 64 * R * D : 1];
-  __shared__ T total[TG * 64 * R * D];  // running sum over the chunks walked so far (kept out of the VGPR budget)
-  const int lane   = threadIdx.x & 63;
-  const int wave   = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tgroup = wave / JS;
-  const int jpart  = wave % JS;
-  T xi[R][D], acc[R][D];
-  // Target block and chunks of this block.  The first `long_blocks` blocks walk ALL chunks of target block blockIdx.x and write
-  // `a`; the rest are the tail: one chunk each of target blocks long_blocks ... long_blocks + tail_blocks - 1 (target block
-  // fastest, so that the blocks in flight stream the same chunk), their sums go to chunk_sums for combine_chunks_kernel.
-  uint32_t tblock = blockIdx.x, y0 = 0, y1 = nchunks;
-  const bool direct = blockIdx.x < long_blocks;
-  if (!direct) {
-    const uint32_t q = blockIdx.x - long_blocks;
-    tblock           = long_blocks + q % tail_blocks;
-    y0               = q / tail_blocks;
-    y1               = y0 + 1;
-  }
-  if constexpr (sizeof(T) == 4) {  // single precision: one chunk per block, in the block shape of rounds 2-3 (see sgpr_single_chunk)
-    sgpr_single_chunk<T, D, R, JS>(packed, x, a, c, sz, first, count, tiles_per_chunk, tblock, y0, long_blocks * TB,
-                                   direct ? static_cast<T*>(nullptr) : chunk_sums, ext, partial);
-    return;
-  }
-  const uint32_t tbase = tblock * TB + tgroup * (64 * R);
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    uint32_t local = tbase + r * 64 + lane;
-    uint64_t i     = uint64_t(first) + (local < count ? local : 0u);
-#pragma unroll
-    for (int k = 0; k < D; ++k) xi[r][k] = x[i * D + k];
-  }
-  // the target loads complete HERE: left to itself hipcc sinks all but the first component's below the first source request
-  // (only xi[0][0] ties the asm in place) and then waits for them — s_waitcnt vmcnt(0) — inside the source loop, every
-  // iteration (f32: +4 % kernel time, measured)
-#pragma unroll
-  for (int r = 0; r < R; ++r)
-#pragma unroll
-    for (int k = 0; k < D; ++k) asm volatile("" : "+v"(xi[r][k]));
-  const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
-  const pair_consts<T> pc;
-  const bool ffar = ap_far_mode<D>(ext);
-  constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
-  struct batch_t {
-    rec_t r[U];
-  };
-  // Two SGPR buffers, each requested (s_load_dwordx16) one compute phase before it is consumed.  Written with inline
-  // asm: hipcc folds a loop-carried load from read-only memory back into a load at the loop top and waits for it there.
-  // SMEM returns out of order, so the only usable wait is lgkmcnt(0): wait for X, request Y, consume X.
-  auto run = [&](auto ff) {  // the chunks of this block, once per pair rule (pair_batch)
-    constexpr bool FF = decltype(ff)::value;
-    for (uint32_t y = y0; y < y1; ++y) {
-      // tiles [t0, t1) of the padded source set; this wave visits its SUB-record slice of every tile, in tile order
-      const uint32_t t0 = y * tiles_per_chunk, t1 = min(ntiles, t0 + tiles_per_chunk);
-      const uint32_t nsteps = (t1 - t0) * SUB;
-      auto batch = [&](uint32_t k) { return packed + (uint64_t(t0 + k / SUB) * kTileJ + uint32_t(jpart) * SUB + (k % SUB)); };
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int k = 0; k < D; ++k) acc[r][k] = T(0);
-      sgpr16 A = sload16(batch(0), xi[0][0]), B;
-      for (uint32_t k = 0; k < nsteps; k += 2 * U) {
-        swait(A, acc[0][0]);
-        B = sload16(batch(k + U), xi[0][0]);
-        {
-          const batch_t ba = __builtin_bit_cast(batch_t, A);
-          pair_batch<T, D, R, U, FF>(acc, xi, ba.r, pc);
-        }
-        swait(B, acc[0][0]);
-        A = sload16(batch(k + 2 * U < nsteps ? k + 2 * U : k), xi[0][0]);  // the last iteration re-requests its own batch
-        {
-          const batch_t bb = __builtin_bit_cast(batch_t, B);
-          pair_batch<T, D, R, U, FF>(acc, xi, bb.r, pc);
-        }
-      }
-      swait(A, acc[0][0]);  // nothing in flight when the wave goes on
-      // Everything lane-dependent the combine needs is derived from `ln` HERE: derived from `lane` it is loop-invariant, and
-      // hipcc then keeps the LDS / output addresses of all R targets in VGPRs across the source loop (f64 R = 1: 70 VGPRs
-      // instead of 64, one block per CU less).
-      int ln = lane;
-      asm volatile("" : "+v"(ln));
-      // s_y: the slices' sums in slice order
-      if constexpr (JS > 1) {
-        if (y > y0) __syncthreads();  // slice 0 has read the previous chunk's partials
-        if (jpart > 0) {
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) partial[((((jpart - 1) * TG + tgroup) * R + r) * D + k) * 64 + ln] = acc[r][k];
-        }
-        __syncthreads();
-        if (jpart == 0) {
-#pragma unroll
-          for (int p = 1; p < JS; ++p)
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-#pragma unroll
-              for (int k = 0; k < D; ++k) acc[r][k] += partial[((((p - 1) * TG + tgroup) * R + r) * D + k) * 64 + ln];
-        }
-      }
-      if (jpart == 0) {
-        if (!direct) {  // this chunk's sum of a tail target, combined in chunk order by combine_chunks_kernel
-          const uint32_t tail_first = long_blocks * TB;  // chunk_sums: T[nchunks][count - tail_first][D]
-          T* out = chunk_sums + uint64_t(y) * (count - tail_first) * D;
-#pragma unroll
-          for (int r = 0; r < R; ++r) {
-            const uint32_t t = tbase + r * 64 + uint32_t(ln);
-            if (t < count) {
-#pragma unroll
-              for (int k = 0; k < D; ++k) out[uint64_t(t - tail_first) * D + k] = acc[r][k];
-            }
-          }
-        } else if (y1 - y0 > 1u) {  // ((s_0 + s_1) + s_2) + ...: the first chunk starts the total, every other one is added to it
-#pragma unroll
-          for (int r = 0; r < R; ++r)
-#pragma unroll
-            for (int k = 0; k < D; ++k) {
-              T* slot = &total[((tgroup * R + r) * D + k) * 64 + ln];
-              if (y > y0) acc[r][k] = *slot + acc[r][k];
-              if (y + 1 < y1) *slot = acc[r][k];
-            }
+        for (int k = 0; k < D; ++k) {
+          T* slot = a + uint64_t(ti[r]) * D + k;
+          T t     = acc[r][k];
+          if (y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
+          if (y == last) t = c * t;
+          if (poisoned) t = __builtin_nan("");
+          __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
     }
-  };
-  if (ffar) run(std::true_type{});  // two copies of the loop: inside ONE loop hipcc hoists the rules' common head above the branch
-  else run(std::false_type{});
-  if (jpart == 0 && direct) {  // all chunks walked here: acc holds the total
-    int ln = lane;
-    asm volatile("" : "+v"(ln));
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint32_t t = tbase + r * 64 + uint32_t(ln);
-      if (t < count) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) a[uint64_t(t) * D + k] = c * acc[r][k];
-      }
-    }
   }
-}
-
-// a = c * (((s_0 + s_1) + s_2) + ...) over the source chunks, in chunk order
-template <typename T>
-__global__ __launch_bounds__(kBlock) void combine_chunks_kernel(const T* __restrict__ chunk_sums, T* __restrict__ a, T c,
-                                                                uint64_t n, uint32_t nchunks) {
-  const uint64_t e = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
-  if (e >= n) return;
-  T sum = chunk_sums[e];
-  for (uint32_t y = 1; y < nchunks; ++y) sum += chunk_sums[uint64_t(y) * n + e];
-  a[e] = c * sum;
+  if (y < last) {  // pass the turn on once the stores above have been acknowledged
+    __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores are at the agent's coherence point
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) __hip_atomic_store(turn + blockIdx.x * TG + tgroup, y + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // Scratch (packed sources; per-chunk sums), one slot per (device, stream) that has called the scalar-stream form (grow-only).  A context
@@ -680,50 +568,11 @@ static int ap_extent(const nbody_state* s, hipStream_t st, const unsigned long l
   return NBODY_OK;
 }
 
-// How many blocks of a kernel the current device holds at once (CUs x blocks per CU), cached per (kernel, device).
-static uint32_t resident_blocks(const void* fn, int threads) {
-  struct entry {
-    const void* fn;
-    int device;
-    uint32_t blocks;
-  };
-  static std::mutex mu;
-  static std::vector<entry> cache;
-  const int dev = current_device();
-  std::lock_guard<std::mutex> lock(mu);
-  for (const auto& e : cache)
-    if (e.fn == fn && e.device == dev) return e.blocks;
-  int per_cu = 0, cus = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-  cache.push_back({fn, dev, uint32_t(per_cu) * uint32_t(cus)});
-  return cache.back().blocks;
-}
-
-// The launch shape of the scalar-stream form (the result does not depend on it).  Walking all chunks in one block needs no
-// chunk-sum scratch and no combine launch, but makes the blocks `chunks` times longer, and the end of a launch is as ragged as
-// its blocks are long: N = 2^20 (8192 target blocks on 512 resident ones, 16 chunks; profiles/r04/k1_walk_tuning.txt, ms per
-// launch on one box, bitwise equal results) 606.6 with one chunk per block, 605.8 / 609.7 / 612.7 with 2 / 4 / 8, 615.7 with all 16
-// in the block; N = 262 144: 37.9 -> 39.1.  So: where the target blocks alone fill the chip for at least four rounds, all but
-// the last `resident` of them walk their chunks themselves, and those last ones — one round's worth of targets — are launched
-// behind them as one-chunk blocks that fill the ragged end (N = 2^20: 7680 long blocks, then 512 x 16 short ones; 25 MB of chunk
-// sums instead of 403 MB).  Smaller launches (a 1/8 shard of 2^20: 1024 target blocks; N = 10^5) stay all short, as since round 2.
-struct sgpr_shape {
-  uint32_t long_blocks = 0, tail_blocks = 0;  // target blocks that walk all chunks; target blocks launched one chunk per block
-};
-template <typename T, int D, int R, int JS>
-static sgpr_shape sgpr_launch_shape(const nbody_state* s, const k1_plan& plan) {
-  constexpr int TB      = (kSgprWaves<JS> / JS) * 64 * R;
-  const uint32_t blocks = (s->count + TB - 1) / TB;
-  sgpr_shape sh;
-  sh.long_blocks = blocks;
-  if (plan.chunks <= 1 || blocks == 0) return sh;
-  const uint32_t slots = resident_blocks(reinterpret_cast<const void*>(&all_pairs_force_sgpr_kernel<T, D, R, JS>), 64 * kSgprWaves<JS>);
-  uint32_t tail        = sizeof(T) == 8 && blocks >= 4u * slots ? slots : blocks;  // f32: one chunk per block throughout (sgpr_single_chunk)
-  if (const char* e = experiment_env("NBODY_K1_TAIL")) tail = uint32_t(atoi(e));  // -DNBODY_EXPERIMENTS builds: A/B runs (target blocks in the tail)
-  sh.tail_blocks = tail < blocks ? tail : blocks;
-  sh.long_blocks = blocks - sh.tail_blocks;
-  return sh;
+// words of the turn array for a launch of `blocks` target blocks (one per target group of a block)
+template <int R, int JS>
+static size_t sgpr_turn_words(uint32_t count) {
+  constexpr int TG = kSgprWaves<JS> / JS, TB = TG * 64 * R;
+  return size_t((count + TB - 1) / TB) * TG;
 }
 
 template <typename T, int D, int R, int JS>
@@ -731,31 +580,22 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  const sgpr_shape sh       = sgpr_launch_shape<T, D, R, JS>(s, plan);
-  const uint32_t tail_first = sh.long_blocks * TB, tail_count = sh.tail_blocks ? s->count - tail_first : 0u;
-  T* sums = nullptr;
-  if (tail_count) {  // before anything is queued: a failed reservation leaves the stream untouched
+  uint32_t* turn = nullptr;
+  if (plan.chunks > 1) {  // before anything is queued: a failed reservation leaves the stream untouched
     void* q = nullptr;
-    if (int r = ap_scratch_get(st, 1, sizeof(T) * size_t(tail_count) * D * plan.chunks, &q)) return r;
-    sums = static_cast<T*>(q);
+    if (int r = ap_scratch_get(st, 1, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), &q)) return r;
+    turn = static_cast<uint32_t*>(q);
   }
   const unsigned long long* ext = nullptr;
   if (int r = ap_extent<T, D>(s, st, &ext)) return r;
   void* scratch = nullptr;
   if (int r = ap_pack_sources(s, st, &scratch)) return r;
   auto* packed = static_cast<src_rec<T, D>*>(scratch);
-  const uint64_t grid = uint64_t(sh.long_blocks) + uint64_t(sh.tail_blocks) * plan.chunks;
-  NB_ARG(grid < (1ull << 31), "all-pairs: %llu blocks exceed the grid limit", (unsigned long long)grid);
-hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(uint32_t(grid)), dim3(64 * kSgprWaves<JS>), 0, st, packed,
-                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                     plan.tiles_per_chunk, plan.chunks, sh.long_blocks, sh.tail_blocks, sums, ext);
+  if (turn) NB_HIP(hipMemsetAsync(turn, 0, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), st));  // chunk 0 needs no turn; 1 is next
+  hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
+                     packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                     plan.tiles_per_chunk, turn, ext);
   NB_HIP(hipGetLastError());
-  if (sums) {
-    const uint64_t n = uint64_t(tail_count) * D;
-    hipLaunchKernelGGL((combine_chunks_kernel<T>), dim3(uint32_t((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, sums,
-                       static_cast<T*>(s->a) + uint64_t(tail_first) * D, static_cast<T>(s->c), n, plan.chunks);
-    NB_HIP(hipGetLastError());
-  }
   return NBODY_OK;
 }
 
@@ -810,17 +650,6 @@ static int all_pairs_dispatch(const nbody_state* s, hipStream_t st) {
   return rc;
 }
 
-// the launch shape for this view; false for the LDS-tile form (no chunks)
-template <typename T, int D>
-static bool all_pairs_shape(const nbody_state* s, const k1_plan& p, sgpr_shape* sh, uint32_t* targets_per_block) {
-  if (!p.scalar) return false;
-  return with_k1_instance(p, [&](auto r, auto js) {
-    constexpr int R = decltype(r)::value, JS = decltype(js)::value;
-    *sh                = sgpr_launch_shape<T, D, R, JS>(s, p);
-    *targets_per_block = (kSgprWaves<JS> / JS) * 64 * R;
-  });
-}
-
 template <typename T, int D>
 static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
   k1_plan p;
@@ -828,24 +657,17 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
   const char* t = sizeof(T) == 8 ? "double" : "float";
   const char* pair = sizeof(T) == 4 ? (s->sz >= kFarMinBodies ? "rsq+rcp[m y^3 at r2 >= 4 if sparse]" : "rsq+rcp")
                                     : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3";
-  sgpr_shape sh;
-  uint32_t tb = 0;
-  if (all_pairs_shape<T, D>(s, p, &sh, &tb)) {
-    char shape[96] = "";
-    if (p.chunks > 1)
-      snprintf(shape, sizeof shape, " blocks=%u walking all chunks + %ux%u one chunk each", sh.long_blocks, sh.tail_blocks, p.chunks);
+  if (p.scalar)
     snprintf(out, len, "all_pairs_force_sgpr_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=%u%s pair=%s", t, D, p.r, p.js, kTileJ, p.chunks,
-             shape, pair);
-  } else {
+             p.chunks > 1 ? "(summed in turn into a)" : "", pair);
+  else
     snprintf(out, len, "all_pairs_force_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=1 pair=%s", t, D, p.r, p.js, kTileJ, pair);
-  }
   return NBODY_OK;
 }
 
 // Everything the K1 launch for this view needs from the stream's scratch slot, reserved ahead (nbody_create,
 // nbody_ctx_set_shard, nbody_ctx_configure_all_pairs) so that a recorded step never allocates: the packed records, the extent
-// keys, and the chunk sums of the target blocks that are launched one chunk per block (N = 2^20, whole system: 25 MB; 403 MB
-// until round 3).
+// keys and the turn words (one per target group: 32 KB at N = 2^20; this slot held 403 MB of chunk sums until round 3).
 int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
   void* q             = nullptr;
   const size_t tsz    = s->dtype == NBODY_F32 ? 4 : 8;
@@ -854,17 +676,13 @@ int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
   if (s->sz >= kFarMinBodies)
     if (int r = ap_scratch_get(st, 3, 64, &q)) return r;
   return dispatch(s->dtype, s->dim, [&](auto tg) {
-    using T         = typename decltype(tg)::type;
-    constexpr int D = decltype(tg)::dim;
+    using T = typename decltype(tg)::type;
     k1_plan p;
     if (int rc = plan_all_pairs<T>(s, &p)) return rc;
-    sgpr_shape sh;
-    uint32_t tb = 0;
-    if (all_pairs_shape<T, D>(s, p, &sh, &tb) && sh.tail_blocks) {
-      const size_t tail_count = size_t(s->count) - size_t(sh.long_blocks) * tb;
-      return ap_scratch_get(st, 1, sizeof(T) * tail_count * D * p.chunks, &q);
-    }
-    return int(NBODY_OK);
+    if (!p.scalar || p.chunks <= 1) return int(NBODY_OK);
+    size_t words = 0;
+    with_k1_instance(p, [&](auto r, auto js) { words = sgpr_turn_words<decltype(r)::value, decltype(js)::value>(s->count); });
+    return words ? ap_scratch_get(st, 1, sizeof(uint32_t) * words, &q) : int(NBODY_OK);
   });
 }
 

@@ -279,6 +279,7 @@ int64_t oracle_build_model(int dtype, int dim, int workload, uint32_t n, void* m
     return n;
   }
   if (workload == 2) {
+    if (n < 2) return -4; /* models.h:112-136 writes the second central mass at index 1 whatever the size */
     uint32_t sz = 0;
 #define CALL(TT, S) sz = model_galaxy_##S(n, (TT*)m, (TT*)x, (TT*)v, dt, c)
     DISPATCH(dtype, dim, CALL);

@@ -251,13 +251,37 @@ __global__ __launch_bounds__(kOB) void ot_bounds_final_kernel(const T* __restric
   }
 }
 
+// Small systems (n <= kSmallN: the reference's default run is 1000 bodies): one block does both halves.  1024: the step of the
+// one-block kernels below is one CU's work — 0.081 ms at n = 1000 (float) against 0.129 through the launches of the large path, but
+// 0.137 at 2048 where the large path (its kernels spread over the chip) takes ~0.12.
+constexpr uint32_t kSmallN = 1024;
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_bounds_small_kernel(const T* __restrict__ x, uint32_t nelem, T* __restrict__ root) {
+#pragma clang fp contract(off)
+  __shared__ T res[2];
+  T lo = T(0), hi = T(0);
+  for (uint32_t e = threadIdx.x; e < nelem; e += kOB) {
+    const T p = x[e];
+    lo        = ot_fmin(lo, p);
+    hi        = ot_fmax(hi, p);
+  }
+  ot_block_minmax(lo, hi, res);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    T mx = res[1], mn = res[0];
+    mx += T(1);
+    mn -= T(1);
+    const T divide = (mx + mn) / T(2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) root[k] = divide;
+    root[D] = mx - mn;
+  }
+}
+
 // ---- path keys (src/octree.h:127-138 replayed per body) ------------------------------------------------------------
 template <typename T, int D>
-__global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, uint32_t n, const T* __restrict__ root,
-                                                      uint64_t* __restrict__ keys) {
+__device__ __forceinline__ uint64_t ot_path_key(const T* __restrict__ x, uint64_t i, const T* __restrict__ root) {
 #pragma clang fp contract(off)
-  const uint64_t i = uint64_t(blockIdx.x) * kOB + threadIdx.x;
-  if (i >= n) return;
   T pos[D], divide[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) {
@@ -278,7 +302,15 @@ __global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, u
     side /= T(2);
     key = (key << D) | cp;
   }
-  keys[i] = key;
+  return key;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kOB) void ot_keys_kernel(const T* __restrict__ x, uint32_t n, const T* __restrict__ root,
+                                                      uint64_t* __restrict__ keys) {
+  const uint64_t i = uint64_t(blockIdx.x) * kOB + threadIdx.x;
+  if (i >= n) return;
+  keys[i] = ot_path_key<T, D>(x, i, root);
 }
 
 // ---- breadth-first build --------------------------------------------------------------------------------------------
@@ -451,13 +483,9 @@ __device__ uint32_t ot_hyperant_at(const T* __restrict__ x, uint32_t body, const
 }
 
 template <typename T, int D>
-__global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict__ sidx, uint32_t* __restrict__ tmp,
-                                                           const T* __restrict__ m,
-                                                           const T* __restrict__ x, const T* __restrict__ root,
-                                                           ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
-                                                           const ot_cell* __restrict__ tops,
-                                                           uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ flags,
-                                                           uint32_t capacity) {
+__device__ __forceinline__ void ot_build_deep_body(uint32_t k0, uint32_t kstride, uint32_t* sidx, uint32_t* tmp, const T* m, const T* x,
+                                                   const T* root, ot_tree<T, D> tree, const ot_cell* cells, const ot_cell* tops,
+                                                   uint32_t* lvl_count, uint32_t* flags, uint32_t capacity) {
 #pragma clang fp contract(off)
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
@@ -473,7 +501,7 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
     uint32_t rank_level;  // level | done << 31 ; rank of a regular (depth ML) cell is implied by its position
   };
   frame stack[kOtDeepFrames];
-  for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < count; k += gridDim.x * 64) {
+  for (uint32_t k = k0; k < count; k += kstride) {
     if (tops == cells + base && base + k >= capacity / NCH + 1u) break;  // the per-level list ran out of room (flagged when it did)
     const ot_cell top = tops[k];
     int sp            = 0;
@@ -577,6 +605,18 @@ __global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict_
       }
     }
   }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(64) void ot_build_deep_kernel(uint32_t* __restrict__ sidx, uint32_t* __restrict__ tmp,
+                                                           const T* __restrict__ m,
+                                                           const T* __restrict__ x, const T* __restrict__ root,
+                                                           ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                           const ot_cell* __restrict__ tops,
+                                                           uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ flags,
+                                                           uint32_t capacity) {
+  ot_build_deep_body<T, D>(blockIdx.x * 64 + threadIdx.x, gridDim.x * 64, sidx, tmp, m, x, root, tree, cells, tops, lvl_count, flags,
+                           capacity);
 }
 
 // ---- multipoles (src/octree.h:205-216) ---------------------------------------------------------------------------------
@@ -963,6 +1003,149 @@ __global__ __launch_bounds__(kLcpBuildB) void ot_build_lcp_kernel(ot_lcp_args<T,
   ot_lcp_cell<T, D>(g, i, d, li, c, 0u);
 }
 
+// Small systems (n <= kSmallN): keys, sort, the pass over the sorted keys, the cells and the cells below the key depth in ONE
+// launch by one block — at this size the step is its launches (13 of them, 0.129 ms at n = 1000, until round 4) and, inside
+// one block, its dependent round trips to memory: the sorted keys and indices, l[], P[] and the rank -> position map stay in
+// LDS and ot_lcp_cell reads them there (the build's chains of dependent loads become LDS latencies; positions and masses in LDS as
+// well — measured — change nothing: what is left of the cells' time is one CU's instruction issue); global memory gets the sorted
+// keys / indices (the walk and nbody_octree_read want them) and what the cells store.  The keys are sorted by the same
+// network as the splitter sort's buckets (the order (key, position) is total, so the permutation is the stable sort's); P[] is
+// the prefix over all positions at once (bbase = 0: rank_at() and the scatter see the same sums as from the blocks of
+// ot_lcp_kernel); the cells are built by rank exactly as ot_build_lcp_kernel does, 2^D lanes each, the deep ones as
+// ot_build_deep_kernel does, a thread each, behind a block barrier with a fence (they read what the block stored).
+constexpr int kSmallB = 1024;
+#ifdef NBODY_EXPERIMENTS
+__device__ uint64_t ot_small_stamps[8];  // wall_clock64() at the phase boundaries of the last launch (100 MHz)
+#define OT_SMALL_STAMP(k) \
+  if (threadIdx.x == 0) ot_small_stamps[k] = wall_clock64()
+#else
+#define OT_SMALL_STAMP(k)
+#endif
+template <typename T, int D>
+__global__ __launch_bounds__(kSmallB) void ot_insert_small_kernel(ot_lcp_args<T, D> g, const T* root, uint64_t* skeys, uint32_t* sidx,
+                                                                 uint32_t* tmp) {
+  constexpr uint32_t NCH = 1u << D;
+  constexpr int ML       = kMaxLevels<D>;
+  __shared__ uint64_t K[kSmallN];
+  __shared__ uint32_t V[kSmallN];
+  __shared__ uint32_t Pl[kSmallN + 1], Rp[kSmallN + 1];
+  __shared__ int8_t Lv[kSmallN + 4];
+  __shared__ uint32_t hist[ML + 1];
+  __shared__ uint32_t wsum[kSmallB / 64];
+  __shared__ uint32_t zero[kSmallN / kLcpB + 1];
+  const uint32_t n = g.n, t = threadIdx.x;
+  OT_SMALL_STAMP(0);
+  constexpr int E = kSmallN / kSmallB;
+  uint64_t key[E];
+  uint32_t pos[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t i = t * E + e;
+    key[e]           = i < n ? ot_path_key<T, D>(g.x, i, root) : ~0ull;
+    pos[e]           = i < n ? i : ~0u;
+  }
+  if (t <= uint32_t(ML)) hist[t] = 0;
+  if (t < kSmallN / kLcpB + 1) zero[t] = 0;
+  OT_SMALL_STAMP(1);
+  uint32_t P = E;
+  while (P < n) P <<= 1;
+  bitonic_sort_regs<kSmallB, E>(key, pos, P, K, V);
+  __syncthreads();  // (K / V may have carried a crossing stage)
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t i = t * E + e;
+    if (i < n) {
+      K[i] = key[e], V[i] = pos[e];
+      skeys[i] = key[e], sidx[i] = pos[e];
+    }
+  }
+  __syncthreads();
+  OT_SMALL_STAMP(2);
+  // positions 0 ... n as in ot_lcp_kernel, kSmallB at a time with the running sum carried along
+  const uint32_t lane = t & 63u, wave = t >> 6;
+  uint32_t carry = 0;
+  for (uint32_t b0 = 0; b0 <= n; b0 += kSmallB) {
+    const uint32_t i = b0 + t;
+    int li = -1, ln = -1;
+    if (i < n) {
+      const uint64_t k = K[i];
+      if (i > 0) li = ot_common_levels<D>(K[i - 1], k);
+      if (i + 1 < n) ln = ot_common_levels<D>(k, K[i + 1]);
+    }
+    if (i <= n) Lv[i] = int8_t(li);
+    const uint32_t cnt = ln > li ? uint32_t(ln - li) : 0u;
+    for (int d = li + 1; d <= ln; ++d) atomicAdd(&hist[d], 1u);
+    uint32_t inc = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t up = __shfl_up(inc, off, 64);
+      if (lane >= uint32_t(off)) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = carry, total = 0;
+#pragma unroll
+    for (int w = 0; w < kSmallB / 64; ++w) {
+      const uint32_t v = wsum[w];
+      if (uint32_t(w) < wave) before += v;
+      total += v;
+    }
+    if (i <= n) Pl[i] = before + inc - cnt;
+    carry += total;
+    __syncthreads();
+  }
+  if (t <= uint32_t(ML)) g.lvl_count[t] = hist[t];
+  if (t == 0) {  // as ot_lcp_finish_kernel
+    g.lvl_count[ML + 1] = 0;
+    g.lvl_count[ML + 5] = 0;
+    g.lvl_count[ML + 6] = 0;
+    if (n < 2) {
+      ot_node<T> r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r.p[k] = T(0);
+#pragma unroll
+      for (int k = 0; k < D; ++k) r.p[k] = g.x[k];
+      r.m   = g.m[0];
+      r.lvl = 0;
+      r.fc  = kOtBody;
+      g.tree.put(0, r);
+    }
+  }
+  for (uint32_t i = t; i < n; i += kSmallB) {  // as ot_lcp_scatter_kernel
+    const int li = Lv[i], ln = Lv[i + 1];
+    if (ln > li) {
+      const uint32_t r0 = Pl[i];
+      for (int q = 0; q < ln - li; ++q)
+        if (r0 + uint32_t(q) < g.max_cells && r0 + uint32_t(q) <= kSmallN) Rp[r0 + uint32_t(q)] = i;
+    }
+  }
+  __threadfence_block();  // (the deep cells' counter, zeroed above, is added to below)
+  __syncthreads();
+  OT_SMALL_STAMP(3);
+  uint32_t total = 0;
+#pragma unroll
+  for (int l = 0; l <= ML; ++l) total += hist[l];
+  if (total > g.max_cells) total = g.max_cells;
+  ot_lcp_args<T, D> gl = g;  // the same build, its inputs read from LDS
+  gl.skeys   = K;
+  gl.sidx    = V;
+  gl.lv      = Lv;
+  gl.plocal  = Pl;
+  gl.bbase   = zero;
+  gl.rankpos = Rp;
+  for (uint32_t r = t / NCH; r < total; r += kSmallB / NCH) {  // as ot_build_lcp_kernel
+    const uint32_t i = Rp[r];
+    const int li     = Lv[i];
+    const int d      = li + 1 + int(r - Pl[i]);
+    if (d < ML) ot_lcp_cell<T, D>(gl, i, d, li, t % NCH, 0u);
+  }
+  __threadfence_block();
+  __syncthreads();
+  OT_SMALL_STAMP(4);
+  ot_build_deep_body<T, D>(t, kSmallB, sidx, tmp, g.m, g.x, root, g.tree, g.cells, g.tops, g.lvl_count, g.flags, g.capacity);
+  OT_SMALL_STAMP(5);
+}
+
 template <typename T, int D>
 __device__ __forceinline__ uint32_t ot_lcp_total(const uint32_t* lvl_count) {
   uint32_t total = 0;
@@ -1028,21 +1211,19 @@ __device__ __forceinline__ void ot_lds_barrier() { asm volatile("s_waitcnt lgkmc
 // loop the only values that are not there yet, the monopoles of child cells, come from LDS, where the block keeps what it has
 // finished.  The cells left to the crown kernel are the ancestors of the next chunk's first cell that lie in this chunk: at
 // most one per level, so they go to the fixed slot (block, level) of `later` and a bit of the block's mask — no counter.
-template <typename T, int D>
-__global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T, D> tree, ot_cell* __restrict__ cells,
-                                                                      const uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ later,
-                                                                      uint32_t* __restrict__ later_mask, uint32_t capacity,
-                                                                      uint32_t max_cells) {
+template <typename T, int D, int CHUNK>
+__device__ __forceinline__ void ot_multipole_chunk_body(uint32_t vblock, T (*sm)[4], ot_tree<T, D> tree, ot_cell* cells,
+                                                        const uint32_t* lvl_count, uint32_t* later, uint32_t* later_mask,
+                                                        uint32_t capacity, uint32_t max_cells) {
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
-  __shared__ T sm[kMpChunk][4];
   __shared__ int lvl_hi, lvl_lo;
   __shared__ uint32_t mask_s;
   uint32_t total = ot_lcp_total<T, D>(lvl_count);
   if (total > max_cells) total = max_cells;
-  const uint32_t first = blockIdx.x * kMpChunk;
+  const uint32_t first = vblock * CHUNK;
   if (first >= total) return;
-  const uint32_t last = first + kMpChunk < total ? first + kMpChunk : total;
+  const uint32_t last = first + CHUNK < total ? first + CHUNK : total;
   if (threadIdx.x == 0) {
     lvl_hi = -1;
     lvl_lo = ML;
@@ -1075,8 +1256,8 @@ __global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T
         slot[c] = cfc[c] < kOtBody && level + 1 < ML ? cfc[c] - first : kMpNone;  // if this cell is (stored fc = group = rank)
       if (wait) {
         atomicOr(&mask_s, 1u << level);
-        later[blockIdx.x * uint32_t(ML) + uint32_t(level)] = r;
-        cells[r].rank = kMpLater | (blockIdx.x * uint32_t(ML) + uint32_t(level));
+        later[vblock * uint32_t(ML) + uint32_t(level)] = r;
+        cells[r].rank = kMpLater | (vblock * uint32_t(ML) + uint32_t(level));
       }
     }
   }
@@ -1095,7 +1276,7 @@ __global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T
   }
   ot_lds_barrier();
   const int hi = lvl_hi, lo = lvl_lo;
-  if (threadIdx.x == 0) later_mask[blockIdx.x] = mask_s;
+  if (threadIdx.x == 0) later_mask[vblock] = mask_s;
   for (int l = hi; l >= lo; --l) {
     if (level == l && !wait) {
       T mass, com[D];
@@ -1115,6 +1296,15 @@ __global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T
     }
     ot_lds_barrier();
   }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T, D> tree, ot_cell* __restrict__ cells,
+                                                                      const uint32_t* __restrict__ lvl_count, uint32_t* __restrict__ later,
+                                                                      uint32_t* __restrict__ later_mask, uint32_t capacity,
+                                                                      uint32_t max_cells) {
+  __shared__ T sm[kMpChunk][4];
+  ot_multipole_chunk_body<T, D, kMpChunk>(blockIdx.x, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
 }
 
 // The waiting cells of a round sit in the slots (block, level) that the blocks' masks name; in (block, level) order they are in
@@ -1292,14 +1482,11 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_round_kernel(ot_tree<T,
 // kMpLater2), deepest level first.  Up to kMpCrown of them: compacted, one per thread, from registers and LDS as above.  More (a
 // pathological tree): level by level, children read from memory.
 template <typename T, int D>
-__global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
-                                                                  const uint32_t* __restrict__ lvl_count,
-                                                                  const uint32_t* __restrict__ later,
-                                                                  const uint32_t* __restrict__ later_mask, uint32_t max_cells,
-                                                                  int after_round) {
+__device__ __forceinline__ void ot_multipole_crown_body(T (*sm)[4], ot_tree<T, D> tree, const ot_cell* cells, const uint32_t* lvl_count,
+                                                        const uint32_t* later, const uint32_t* later_mask, uint32_t max_cells,
+                                                        int after_round) {
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
-  __shared__ T sm[kMpCrown][4];
   __shared__ uint32_t base[kMpMaxBlocks + 1];
   __shared__ uint32_t wsum[kMpCrown / 64];
   __shared__ uint32_t carry_s;
@@ -1375,6 +1562,48 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T,
     __threadfence_block();
     __syncthreads();  // (waits for the stores: the next level reads them back)
   }
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(kMpCrown) void ot_multipole_crown_kernel(ot_tree<T, D> tree, const ot_cell* __restrict__ cells,
+                                                                  const uint32_t* __restrict__ lvl_count,
+                                                                  const uint32_t* __restrict__ later,
+                                                                  const uint32_t* __restrict__ later_mask, uint32_t max_cells,
+                                                                  int after_round) {
+  __shared__ T sm[kMpCrown][4];
+  ot_multipole_crown_body<T, D>(sm, tree, cells, lvl_count, later, later_mask, max_cells, after_round);
+}
+
+// Small systems (at most kSmallChunks chunks of ranks) in one launch by one block: the chunks one after the other and the crown —
+// or, in float, where a cell's 2^D child records fit the registers of 1024 threads, and the tree has at most 1024
+// cells, ONE chunk of 1024 ranks and nothing left for a crown.  The crown reads what the chunks stored (records, marks, slots): a fence and a
+// full barrier in between.
+constexpr uint32_t kSmallChunks = (kSmallN + 1 + kMpChunk - 1) / kMpChunk;
+static_assert(kMpChunk == kMpCrown, "the small-tree kernel runs both bodies with one block shape");
+template <typename T, int D>
+constexpr int kSmallMpThreads = sizeof(T) == 4 ? 1024 : kMpChunk;  // (double: 3D does not fit the registers, 2D not the 64 KB of static LDS)
+template <typename T, int D>
+__global__ __launch_bounds__((kSmallMpThreads<T, D>)) void ot_multipole_small_kernel(ot_tree<T, D> tree, ot_cell* cells, const uint32_t* lvl_count,
+                                                                                  uint32_t* later, uint32_t* later_mask, uint32_t capacity,
+                                                                                  uint32_t max_cells, uint32_t max_chunks) {
+  constexpr int NT = kSmallMpThreads<T, D>;
+  __shared__ T sm[NT][4];
+  uint32_t total = ot_lcp_total<T, D>(lvl_count);
+  if (total > max_cells) total = max_cells;
+  if (NT > kMpChunk && total <= uint32_t(NT)) {
+    ot_multipole_chunk_body<T, D, NT>(0, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
+    return;
+  }
+  if (threadIdx.x >= uint32_t(kMpChunk)) return;  // (the chunks of kMpChunk ranks and the crown are written for kMpChunk threads)
+  const uint32_t chunks = (total + kMpChunk - 1) / kMpChunk;
+  for (uint32_t b = 0; b < chunks && b < max_chunks; ++b) {
+    ot_multipole_chunk_body<T, D, kMpChunk>(b, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
+    if (chunks > 1) {
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  if (chunks > 1) ot_multipole_crown_body<T, D>(sm, tree, cells, lvl_count, later, later_mask, max_cells, 0);
 }
 
 // ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------
@@ -2261,6 +2490,12 @@ static int ot_check(const nbody_octree* t, const nbody_state* s, void* stream) {
 
 template <typename T, int D>
 static int ot_bounds_run(nbody_octree* t, const nbody_state* s, hipStream_t st) {
+  if (s->sz <= kSmallN) {
+    hipLaunchKernelGGL((ot_bounds_small_kernel<T, D>), dim3(1), dim3(kOB), 0, st, static_cast<const T*>(s->x), s->sz * uint32_t(D),
+                       static_cast<T*>(t->root));
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
   hipLaunchKernelGGL((ot_bounds_partial_kernel<T>), dim3(t->bounds_blocks), dim3(kOB), 0, st, static_cast<const T*>(s->x),
                      uint64_t(s->sz) * D, static_cast<T*>(t->partials));
   NB_HIP(hipGetLastError());
@@ -2275,6 +2510,16 @@ static int ot_insert_run(nbody_octree* t, const nbody_state* s, hipStream_t st) 
   constexpr uint32_t NCH = 1u << D;
   const uint32_t n       = s->sz;
   const ot_tree<T, D> tree{static_cast<ot_group<T, D>*>(t->groups), static_cast<ot_node<T>*>(t->rootrec)};
+  if (n <= kSmallN && (t->build == 0 || t->build == 3)) {  // one block does everything up to the cells
+    uint32_t* flags = t->lvl_count + (kMaxLevels<D> + 2);
+    const ot_lcp_args<T, D> args{t->keys[0], t->idx[0], n, t->lcp, t->plocal, t->bsum, t->rankpos, static_cast<const T*>(s->m),
+                                 static_cast<const T*>(s->x), tree, t->cells, t->tops, t->lvl_count, flags, t->capacity, t->max_cells};
+    hipLaunchKernelGGL((ot_insert_small_kernel<T, D>), dim3(1), dim3(kSmallB), 0, st, args, static_cast<const T*>(t->root), t->keys[0],
+                       t->idx[0], t->idx[1]);
+    NB_HIP(hipGetLastError());
+    t->sorted_buf = 0;
+    return NBODY_OK;
+  }
   hipLaunchKernelGGL((ot_keys_kernel<T, D>), dim3((n + kOB - 1) / kOB), dim3(kOB), 0, st, static_cast<const T*>(s->x), n,
                      static_cast<const T*>(t->root), t->keys[0]);
   NB_HIP(hipGetLastError());
@@ -2358,6 +2603,12 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
                          t->cells, t->lvl_count, t->capacity, t->max_cells);
       NB_HIP(hipGetLastError());
     }
+    return NBODY_OK;
+  }
+  if ((t->build == 0 || t->build == 3) && max_chunks <= kSmallChunks) {
+    hipLaunchKernelGGL((ot_multipole_small_kernel<T, D>), dim3(1), dim3((kSmallMpThreads<T, D>)), 0, st, tree, t->cells, t->lvl_count, t->later,
+                       t->later_mask, t->capacity, t->max_cells, max_chunks);
+    NB_HIP(hipGetLastError());
     return NBODY_OK;
   }
   if (t->build == 0 || t->build == 3) {  // rank chunks, then the cells that span chunk boundaries: in one block, or in two rounds
@@ -2486,6 +2737,16 @@ extern "C" int nbody_octree_set_build(nbody_octree* t, int mode) {
   if (mode != 4) t->depth_hint = 64;  // 1: every level its own launch, whatever earlier trees looked like
   return NBODY_OK;
 }
+
+#ifdef NBODY_EXPERIMENTS
+// wall_clock64() stamps (100 MHz) of the last ot_insert_small_kernel launch on the current device: entry, keys, sort, numbering,
+// cells, deep cells (tools/time_small_insert_phases.py)
+extern "C" int nbody_exp_octree_small_stamps(uint64_t* out8) {
+  NB_HIP(hipDeviceSynchronize());
+  NB_HIP(hipMemcpyFromSymbol(out8, HIP_SYMBOL(nbody::ot_small_stamps), sizeof(uint64_t) * 8));
+  return NBODY_OK;
+}
+#endif
 
 extern "C" int nbody_octree_set_step_budget(nbody_octree* t, uint32_t steps) {
   NB_ARG(t != nullptr, "nbody_octree is NULL");

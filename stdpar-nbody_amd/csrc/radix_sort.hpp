@@ -1,16 +1,17 @@
 // Sort of (u64 key, u32 index) pairs by (key, original position) — shared by the Hilbert BVH (K6, replaces std::sort at
 // src/bvh.h:55-94) and the octree build.  The order is total (positions are distinct), so every correct sort produces the same
 // permutation bit for bit; three forms, by size:
-//   * n <= 2048: all passes of a stable LSD radix sort in one launch (radix_sort_one_block_kernel);
+//   * n <= 2048: one block, a bitonic network over pairs held in registers (bitonic_sort_one_block_kernel);
 //   * up to 1.5 M pairs: a SPLITTER sort in five launches (round 4; 24 before): B - 1 splitters from a regular sample of the input
 //     sorted by one block, one counting pass + row scan + scatter into the B buckets (the "digit" of a pair is its bucket), then
-//     every bucket sorted by one block in LDS.  Buckets follow the data's own quantiles, so clustered keys (a galaxy inside a box
+//     every bucket sorted by one block (a bitonic network over pairs held in registers).  Buckets follow the data's own quantiles, so clustered keys (a galaxy inside a box
 //     inflated by escapers: most keys share their top 30 bits) cost nothing extra, and ties are broken by position, so equal keys
 //     cannot overfill a bucket;
 //   * beyond: stable LSD radix sort, 8 bits per pass (per-block digit histogram, per-digit row scan, stable scatter by wave
 //     match-any ranking with the 256-digit base scan folded in): 24 launches.
 // Kernels are `static` so both translation units can include this header.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace nbody {
@@ -155,89 +156,6 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
 }
 
 
-// A sort that fits ONE block's tile (n <= 2048: the reference's default run is 1000 bodies) does all its passes in one launch: the
-// block's own digit counts are the whole histogram, and a block barrier separates the passes (the pairs ping-pong through the
-// same two global buffers; a block's stores are visible to its own later loads).  16 dependent launches were half of the octree
-// step at that size.
-static __global__ __launch_bounds__(kSortB) void radix_sort_one_block_kernel(uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
-                                                                             uint32_t* __restrict__ i0, uint32_t* __restrict__ i1,
-                                                                             uint32_t n, int key_bits) {
-  __shared__ uint32_t wcnt[kSortB / 64][256];
-  __shared__ uint32_t dbase[256], dtot[256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (1ull << lane) - 1ull;
-  int pass = 0;
-  for (int shift = 0; shift < key_bits; shift += 8, ++pass) {
-    const uint64_t* kin  = (pass & 1) ? k1 : k0;
-    uint64_t* kout       = (pass & 1) ? k0 : k1;
-    const uint32_t* iin  = pass == 0 ? nullptr : ((pass & 1) ? i1 : i0);  // first pass: payload = position
-    uint32_t* iout       = (pass & 1) ? i0 : i1;
-    for (int q = threadIdx.x; q < (kSortB / 64) * 256; q += kSortB) (&wcnt[0][0])[q] = 0;
-    __syncthreads();
-    uint64_t key[kSortIPT];
-    uint32_t pay[kSortIPT], rank[kSortIPT];
-#pragma unroll
-    for (int s = 0; s < kSortIPT; ++s) {
-      const uint32_t i = wave * (64 * kSortIPT) + s * 64 + lane;
-      const bool valid = i < n;
-      key[s]           = valid ? kin[i] : 0ull;
-      pay[s]           = valid ? (iin ? iin[i] : i) : 0u;
-      const uint32_t d = uint32_t(key[s] >> shift) & 255u;
-      uint64_t same    = __ballot(valid);
-#pragma unroll
-      for (int b = 0; b < 8; ++b) {
-        const bool bit      = (d >> b) & 1u;
-        const uint64_t vote = __ballot(valid && bit);
-        same &= bit ? vote : ~vote;
-      }
-      const uint32_t before = __popcll(same & lt_mask);
-      const uint32_t base   = wcnt[wave][d];
-      rank[s]               = base + before;
-      __builtin_amdgcn_wave_barrier();
-      if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
-      __builtin_amdgcn_wave_barrier();
-    }
-    __syncthreads();
-    {  // digit = threadIdx.x: its total over the waves, then the exclusive scan over the digits
-      uint32_t v = 0;
-#pragma unroll
-      for (int w = 0; w < kSortB / 64; ++w) v += wcnt[w][threadIdx.x];
-      dtot[threadIdx.x] = v;
-      uint32_t inc      = v;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        uint32_t o = __shfl_up(inc, off, 64);
-        if (lane >= off) inc += o;
-      }
-      dbase[threadIdx.x] = inc - v;
-    }
-    __syncthreads();
-    {
-      uint32_t run = dbase[threadIdx.x];
-      for (int w = 0; w < wave; ++w) run += dbase[w * 64 + 63] + dtot[w * 64 + 63];  // totals of the earlier 64-digit groups
-#pragma unroll
-      for (int w = 0; w < kSortB / 64; ++w) {
-        uint32_t cw          = wcnt[w][threadIdx.x];
-        wcnt[w][threadIdx.x] = run;
-        run += cw;
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int s = 0; s < kSortIPT; ++s) {
-      const uint32_t i = wave * (64 * kSortIPT) + s * 64 + lane;
-      if (i < n) {
-        const uint32_t d   = uint32_t(key[s] >> shift) & 255u;
-        const uint32_t pos = wcnt[wave][d] + rank[s];
-        kout[pos]          = key[s];
-        iout[pos]          = pay[s];
-      }
-    }
-    __threadfence_block();
-    __syncthreads();  // the next pass reads what this one wrote
-  }
-}
-
 // ------------------------------------------------------------------------------------------------
 // Splitter sort (2048 < n <= kSplitterMaxN).
 // ------------------------------------------------------------------------------------------------
@@ -256,15 +174,12 @@ __host__ __device__ inline uint32_t splitter_buckets(uint32_t n) {  // power of 
 
 __device__ __forceinline__ bool pair_less(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) { return ka < kb || (ka == kb && ia < ib); }
 
-// Bitonic sorting network in the all-ascending ("flip / disperse") form over p[0 .. P), P a power of two, of which only the
-// first n hold pairs: the rest count as +infinity, and since every exchange leaves the smaller pair at the lower index an
-// exchange whose upper index is >= n is a no-op and is skipped.  K / V may be LDS or global pointers.  Pair number t of a stage
-// is handled by thread t mod NT, and the pairs 64 q .. 64 q + 63 of every stage whose exchanges span at most 128 elements touch
-// exactly the elements 128 q .. 128 q + 127: consecutive such stages are one wave's own business and need no block barrier
-// (P = 4096: 20 block barriers instead of 78 — the barriers were most of the kernels' time).  The caller has made the input
-// visible to the block; on return the output is.
-template <int NT, bool GLOBAL>
-__device__ __forceinline__ void bitonic_sort_pairs(uint64_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t P, uint32_t n) {
+// Bitonic sorting network in the all-ascending ("flip / disperse") form over p[0 .. P) IN GLOBAL MEMORY, P a power of two, of which
+// only the first n hold pairs: the rest count as +infinity, and since every exchange leaves the smaller pair at the lower index an
+// exchange whose upper index is >= n is a no-op and is skipped.  The slow path of a bucket that outgrows LDS (an input whose
+// regular sample misrepresents it): a fence and a block barrier per stage.
+template <int NT>
+__device__ __forceinline__ void bitonic_sort_global(uint64_t* __restrict__ K, uint32_t* __restrict__ V, uint32_t P, uint32_t n) {
   auto exchange = [&](uint32_t i, uint32_t j) {
     if (j < n) {
       const uint64_t ki = K[i], kj = K[j];
@@ -275,34 +190,148 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* __restrict__ K, uin
       }
     }
   };
-  bool prev_local = false;
-  auto sync = [&](bool local) {  // before a stage: its inputs were written by this wave alone iff it and the stage before are local
-    if (local && prev_local) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-    } else {
-      if (GLOBAL) __threadfence_block();
-      __syncthreads();
-    }
-    prev_local = local;
-  };
   for (uint32_t k = 2; k <= P; k <<= 1) {
     const uint32_t half = k >> 1;
-    sync(!GLOBAL && k <= 128u);
+    __threadfence_block();
+    __syncthreads();
     for (uint32_t t = threadIdx.x; t < P / 2; t += NT) {  // flip: i against the mirror position in its k-block
       const uint32_t base = (t / half) * k, r = t % half;
       exchange(base + r, base + k - 1 - r);
     }
     for (uint32_t j = k >> 2; j >= 1; j >>= 1) {  // disperse
-      sync(!GLOBAL && j <= 64u);
+      __threadfence_block();
+      __syncthreads();
       for (uint32_t t = threadIdx.x; t < P / 2; t += NT) {
         const uint32_t i = 2 * j * (t / j) + t % j;
         exchange(i, i + j);
       }
     }
   }
-  if (GLOBAL) __threadfence_block();
+  __threadfence_block();
   __syncthreads();
+}
+
+// The same order by ONE borrow chain over the 96-bit number key:position (three full-rate instructions and their wait
+// states; the compiler's version of pair_less is three 64-bit compares and their selects).
+__device__ __forceinline__ bool pair_less_chain(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib) {
+  uint64_t mask;
+  uint32_t t;
+  asm("v_sub_co_u32_e32 %1, vcc, %2, %3\n\t"
+      "s_nop 1\n\t"  // (gfx940: a VALU that reads VCC needs two wait states behind the VALU that wrote it, carries included)
+      "v_subb_co_u32_e32 %1, vcc, %4, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %6, %7, vcc\n\t"
+      "s_mov_b64 %0, vcc"
+      : "=s"(mask), "=&v"(t)
+      : "v"(ia), "v"(ib), "v"(uint32_t(ka)), "v"(uint32_t(kb)), "v"(uint32_t(ka >> 32)), "v"(uint32_t(kb >> 32))
+      : "vcc");
+  return __builtin_amdgcn_inverse_ballot_w64(mask);
+}
+
+// Bitonic sorting network with the pairs in REGISTERS: thread t of NT holds the elements t E ... t E + E - 1 of p[0 .. NT E) and
+// the aligned block p[0 .. P) comes out ascending (P a power of two, E <= P <= NT E; elements that are not there are
+// (~0, ~0): greater than every pair).  Of the log P (log P + 1) / 2 stages, those whose partner is in the same thread are
+// compare-exchanges between registers, those whose partner is in the same wave move the partner's pair through
+// ds_bpermute (no LDS storage, no barrier), and only the stages that cross waves (distance >= 64 E) go through LDS behind
+// block barriers: P = 4096 with 1024 threads: 10 of 78.  Measured against the same network with the pairs in LDS (a barrier or
+// a wave fence per stage), round 4: the 4096 sample pairs 53 -> 42 us, the 1000 pairs of the one-block octree insert 14.9 -> 12.8,
+// the bucket kernel 72 -> 68 (N = 10^6) and 24.6 -> 22.7 (10^5).  Either form is a chain of log P (log P + 1) / 2 dependent
+// stages of ~0.2 us (a ds_bpermute or LDS round trip, the compare, the selects): the stage count, not the traffic, is the time.
+// Ks / Vs: NT E pairs of LDS for the crossing stages.  Every thread of the block must call (block barriers inside).
+template <int NT, int E>
+__device__ __forceinline__ void bitonic_sort_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint32_t P, uint64_t* Ks, uint32_t* Vs) {
+  const uint32_t t = threadIdx.x, lane = t & 63u;
+  auto exchange = [&](int a, int b, bool asc) {  // (a, b) ascending if asc, descending if not
+    const bool sw    = pair_less_chain(k[b], v[b], k[a], v[a]) == asc;
+    const uint64_t x = k[a];
+    const uint32_t y = v[a];
+    k[a] = sw ? k[b] : x, v[a] = sw ? v[b] : y;
+    k[b] = sw ? x : k[b], v[b] = sw ? y : v[b];
+  };
+#pragma unroll
+  for (int kk = 2; kk <= E; kk <<= 1) {
+#pragma unroll
+    for (int j = kk >> 1; j >= 1; j >>= 1) {
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if ((e & j) == 0) exchange(e, e | j, ((t * E + e) & uint32_t(kk)) == 0);
+    }
+  }
+  const bool active = (t & ~63u) * E < P;  // the wave holds elements of the block
+  for (uint32_t kk = 2 * E; kk <= P; kk <<= 1) {
+    const bool asc = ((t * E) & kk) == 0;
+    for (uint32_t j = kk >> 1; j >= uint32_t(E); j >>= 1) {
+      const uint32_t s    = j / E;                 // the partner is thread t ^ s, same register
+      const bool keep_min = ((t & s) == 0) == asc;
+      if (s >= 64u) {
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) Ks[e * NT + t] = k[e], Vs[e * NT + t] = v[e];
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+          for (int e = 0; e < E; ++e) {
+            const uint64_t pk = Ks[e * NT + (t ^ s)];
+            const uint32_t pv = Vs[e * NT + (t ^ s)];
+            const bool take   = pair_less_chain(pk, pv, k[e], v[e]) == keep_min;
+            k[e] = take ? pk : k[e], v[e] = take ? pv : v[e];
+          }
+        }
+        __syncthreads();
+      } else if (active) {
+        const int src = int((lane ^ s) << 2);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint32_t pl = uint32_t(__builtin_amdgcn_ds_bpermute(src, int(uint32_t(k[e]))));
+          const uint32_t ph = uint32_t(__builtin_amdgcn_ds_bpermute(src, int(uint32_t(k[e] >> 32))));
+          const uint32_t pv = uint32_t(__builtin_amdgcn_ds_bpermute(src, int(v[e])));
+          const uint64_t pk = (uint64_t(ph) << 32) | pl;
+          const bool take   = pair_less_chain(pk, pv, k[e], v[e]) == keep_min;
+          k[e] = take ? pk : k[e], v[e] = take ? pv : v[e];
+        }
+      }
+    }
+    if (active) {
+#pragma unroll
+      for (int j = E >> 1; j >= 1; j >>= 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if ((e & j) == 0) exchange(e, e | j, asc);
+      }
+    }
+  }
+}
+
+// A sort that fits ONE block (n <= 2048: the reference's default run is 1000 bodies): the network above over one or two pairs per
+// thread, from (k0, position) into (k1, i1).  (Until round 4 all eight passes of the LSD radix sort in one launch: 44.6 us at
+// n = 2048 against 22 for the network; 16 dependent launches before that.)
+constexpr int kOneBlockThreads = 1024;
+static __global__ __launch_bounds__(kOneBlockThreads) void bitonic_sort_one_block_kernel(const uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
+                                                                                         uint32_t* __restrict__ i1, uint32_t n) {
+  __shared__ uint64_t K[2 * kOneBlockThreads];
+  __shared__ uint32_t V[2 * kOneBlockThreads];
+  auto sort_with = [&](auto width) {
+    constexpr int E = decltype(width)::value;
+    uint64_t k[E];
+    uint32_t v[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t q = threadIdx.x * E + e;
+      k[e]             = q < n ? k0[q] : ~0ull;
+      v[e]             = q < n ? q : ~0u;
+    }
+    uint32_t P = E;
+    while (P < n) P <<= 1;
+    bitonic_sort_regs<kOneBlockThreads, E>(k, v, P, K, V);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const uint32_t q = threadIdx.x * E + e;
+      if (q < n) k1[q] = k[e], i1[q] = v[e];
+    }
+  };
+  if (n <= uint32_t(kOneBlockThreads)) sort_with(std::integral_constant<int, 1>{});
+  else sort_with(std::integral_constant<int, 2>{});
 }
 
 // S1: the splitters.  One block sorts m = splitter_sample(B) pairs taken at a regular stride from the input and keeps every
@@ -312,19 +341,27 @@ __device__ __forceinline__ void bitonic_sort_pairs(uint64_t* __restrict__ K, uin
 static __global__ __launch_bounds__(kSampleThreads) void splitter_sample_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B,
                                                                                 uint64_t* __restrict__ split_key,
                                                                                 uint32_t* __restrict__ split_idx) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int E = kSampleMax / kSampleThreads;
+  __shared__ uint64_t K[kSampleMax];
+  __shared__ uint32_t V[kSampleMax];
   const uint32_t m = splitter_sample(B), every = m / B;
-  uint64_t* K      = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* V      = reinterpret_cast<uint32_t*>(K + m);
-  for (uint32_t q = threadIdx.x; q < m; q += kSampleThreads) {
-    const uint32_t i = uint32_t((uint64_t(q) * n + n / 2) / m);  // < n
-    K[q]             = keys[i];
-    V[q]             = i;
+  uint64_t k[E];
+  uint32_t v[E];
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const uint32_t q = threadIdx.x * E + e;
+    const uint32_t i = q < m ? uint32_t((uint64_t(q) * n + n / 2) / m) : 0u;  // < n
+    k[e]             = q < m ? keys[i] : ~0ull;
+    v[e]             = q < m ? i : ~0u;
   }
-  bitonic_sort_pairs<kSampleThreads, false>(K, V, m, m);
-  for (uint32_t b = threadIdx.x + 1; b < B; b += kSampleThreads) {  // bucket b holds the pairs p with splitter[b-1] <= p < splitter[b]
-    split_key[b - 1] = K[every * b];
-    split_idx[b - 1] = V[every * b];
+  bitonic_sort_regs<kSampleThreads, E>(k, v, m < uint32_t(E) ? uint32_t(E) : m, K, V);
+#pragma unroll
+  for (int e = 0; e < E; ++e) {  // bucket b holds the pairs p with splitter[b-1] <= p < splitter[b]
+    const uint32_t q = threadIdx.x * E + e;
+    if (q < m && q >= every && q % every == 0) {
+      split_key[q / every - 1] = k[e];
+      split_idx[q / every - 1] = v[e];
+    }
   }
 }
 
@@ -437,8 +474,10 @@ static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const u
   }
 }
 
-// S5: one block per bucket sorts it — in LDS up to kBucketCap pairs, in place in global memory beyond (a bucket that large takes
-// an input whose regular sample misrepresents it; correct, slow) — and writes it to the output buffers at the same positions.
+// S5: one block per bucket sorts it — in registers up to kBucketCap pairs (2, 4 or 8 per thread by the bucket's size), in place in
+// global memory beyond (a bucket that large takes an input whose regular sample misrepresents it; correct, slow) — and writes it
+// to the output buffers at the same positions.  (One block per bucket, not a loop over buckets in fewer blocks: 256 ... 2048 blocks
+// for 2048 buckets time the same.)
 // (The rank-by-comparison form of S1's note was measured here too: 217 us against 22-36 at N = 10^5, 592 against 77-102 at 10^6.)
 static __global__ __launch_bounds__(kBucketThreads) void splitter_bucket_sort_kernel(uint64_t* __restrict__ keys_in, uint32_t* __restrict__ idx_in,
                                                                                      uint64_t* __restrict__ keys_out,
@@ -450,12 +489,29 @@ static __global__ __launch_bounds__(kBucketThreads) void splitter_bucket_sort_ke
   if (cnt == 0) return;
   uint32_t P = 1;
   while (P < cnt) P <<= 1;
-  if (cnt <= kBucketCap) {
-    for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) K[q] = keys_in[start + q], V[q] = idx_in[start + q];
-    bitonic_sort_pairs<kBucketThreads, false>(K, V, P, cnt);
-    for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) keys_out[start + q] = K[q], idx_out[start + q] = V[q];
+  if (cnt <= kBucketCap) {  // as few pairs per thread as the bucket allows: the network is a chain of dependent stages, and waves side by side hide it
+    auto sort_with = [&](auto width) {
+      constexpr int E = decltype(width)::value;
+      uint64_t k[E];
+      uint32_t v[E];
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t q = threadIdx.x * E + e;
+        k[e]             = q < cnt ? keys_in[start + q] : ~0ull;
+        v[e]             = q < cnt ? idx_in[start + q] : ~0u;
+      }
+      bitonic_sort_regs<kBucketThreads, E>(k, v, P < uint32_t(E) ? uint32_t(E) : P, K, V);
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t q = threadIdx.x * E + e;
+        if (q < cnt) keys_out[start + q] = k[e], idx_out[start + q] = v[e];
+      }
+    };
+    if (P <= 2u * kBucketThreads) sort_with(std::integral_constant<int, 2>{});
+    else if (P <= 4u * kBucketThreads) sort_with(std::integral_constant<int, 4>{});
+    else sort_with(std::integral_constant<int, int(kBucketCap / kBucketThreads)>{});
   } else {
-    bitonic_sort_pairs<kBucketThreads, true>(keys_in + start, idx_in + start, P, cnt);
+    bitonic_sort_global<kBucketThreads>(keys_in + start, idx_in + start, P, cnt);
     for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) keys_out[start + q] = keys_in[start + q], idx_out[start + q] = idx_in[start + q];
   }
 }
@@ -490,9 +546,9 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
                             int* final_buf) {
   const uint32_t nblk    = radix_sort_blocks(n);
   if (nblk == 1) {
-    hipLaunchKernelGGL(radix_sort_one_block_kernel, dim3(1), dim3(kSortB), 0, st, keys[0], keys[1], idx[0], idx[1], n, key_bits);
+    hipLaunchKernelGGL(bitonic_sort_one_block_kernel, dim3(1), dim3(kOneBlockThreads), 0, st, keys[0], keys[1], idx[1], n);
     NB_HIP(hipGetLastError());
-    *final_buf = ((key_bits + 7) / 8) & 1;
+    *final_buf = 1;
     return NBODY_OK;
   }
   if (n <= kSplitterMaxN) {  // splitter sort: pairs start in (keys[0], position), go through (keys[1], idx[1]) bucketed, end in (keys[0], idx[0])
@@ -504,7 +560,7 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
     uint32_t* split_idx    = bucket_start + B + 1;
     uint64_t* split_key    = reinterpret_cast<uint64_t*>(split_idx + B + 1);  // 8-byte aligned: hist is, and B (sblk + 3) + 2 words is even
     uint16_t* bucket       = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(split_key) + 2 * size_t(B));
-    hipLaunchKernelGGL(splitter_sample_kernel, dim3(1), dim3(kSampleThreads), splitter_sample(B) * 12u, st, keys[0], n, B, split_key, split_idx);
+    hipLaunchKernelGGL(splitter_sample_kernel, dim3(1), dim3(kSampleThreads), 0, st, keys[0], n, B, split_key, split_idx);
     NB_HIP(hipGetLastError());
     if (n <= kSplitSmallN)
       hipLaunchKernelGGL(splitter_count_kernel<2>, dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);

@@ -106,6 +106,8 @@ void add_disc(System<T, D>& sys, std::size_t count, T central_mass, T disc_mass,
 // The system holds 2*(size/2.0) bodies (truncated), each disc has size/2 - 1 orbiters.
 template <typename T, int D>
 System<T, D> make_galaxy(std::size_t count) {
+  // (the reference writes its second central mass past the end of a one-body system; refused here)
+  if (count < 2) throw std::invalid_argument("the galaxy workload needs at least 2 bodies (one central mass per disc)");
   double const half = count / 2.0;
   System<T, D> sys(static_cast<std::uint32_t>(2 * half), T(1e1), T(1e-4));
   T central      = 1e4;

@@ -52,6 +52,46 @@ def test_octree_force_phase_vs_oracle(nb, oracle, dtype, dim):
             dev.close()
 
 
+@pytest.mark.parametrize("dtype", [1, 0])
+@pytest.mark.parametrize("dim", [3, 2])
+def test_octree_small_systems_one_block_step(nb, oracle, dtype, dim):
+    """Systems of up to 1024 bodies (the reference's default run is 1000) are built by ONE block in one launch (bounds in one, keys
+    + sort + numbering + cells + deep cells in one, monopoles in one): tree size, root monopole and per-body visit counters bit for
+    bit against the oracle on both sides of that limit, the accelerations within the force tolerance and bitwise equal to the
+    breadth-first build's, and 30 steps of the step loop bitwise equal between the two build forms (the tree object is reused:
+    whatever one step leaves in the buffers the next must not depend on)."""
+    for wl, n in (("uniform", 1), ("uniform", 2), ("uniform", 3), ("galaxy", 257), ("galaxy", 1000), ("uniform", 1024), ("uniform", 1025),
+                  ("galaxy", 2048)):
+        ref = oracle.build_model(dtype, dim, wl, n)
+        ocnt, osize, omass = oracle.octree_step_force(ref, 0.5, want_counts=True)
+        acc = []
+        for form in (3, 1):
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
+            dev.octree.set_build(form)
+            dev.octree.enable_counters(True)
+            dev.octree_force(0.5)
+            dev.sync()
+            assert dev.octree.info(dev.stream) == (osize, omass), (wl, n, form)
+            assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt), (wl, n, form)
+            acc.append(dev.download().a.copy())
+            assert maxrel(acc[-1], ref.a) <= FORCE_TOL[dtype] or n == 1, (wl, n, form)
+            dev.close()
+        assert np.array_equal(acc[0], acc[1]), (wl, n)
+    for n in (1000, 1024):
+        out = []
+        for form in (3, 1):
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, "galaxy", n))
+            dev.octree.set_build(form)
+            for _ in range(30):
+                dev.octree_force(0.5)
+                dev.accelerate_step()
+            dev.sync()
+            dev.octree.info(dev.stream)
+            out.append(dev.download())
+            dev.close()
+        assert np.array_equal(out[0].x, out[1].x) and np.array_equal(out[0].v, out[1].v), n
+
+
 def test_octree_force_is_deterministic(nb):
     """Two runs on fresh trees give the same bits (the build's node numbering may differ between runs; the walk does not
     depend on it), and a body's result does not depend on which other bodies share its wave."""

@@ -34,6 +34,17 @@ def test_plummer_needs_3d(nb):
         nb.build_model(nb.F64, 2, "plummer", 8)
 
 
+def test_one_body_galaxy_is_refused(nb, oracle):
+    """models.h:112-136 places one central mass per disc — index 1 of a one-body system is past its end (the reference writes there).
+    The generator and the oracle refuse instead; two bodies are the two central masses."""
+    with pytest.raises(nb.NbodyError):
+        nb.build_model(nb.F64, 3, "galaxy", 1)
+    with pytest.raises(RuntimeError):
+        oracle.build_model(1, 3, "galaxy", 1)
+    h, o = nb.build_model(nb.F64, 3, "galaxy", 2), oracle.build_model(1, 3, "galaxy", 2)
+    assert h.m.tolist() == [1e4, 1e3] and np.array_equal(h.x, o.x)
+
+
 def _cli(dim):
     p = os.path.join(ROOT, "stdpar-nbody_amd", "bin", f"nbody_hip_d{dim}")
     if not os.path.exists(p):

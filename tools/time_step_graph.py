@@ -1,10 +1,10 @@
 """Diagnostic: ms per whole step of the tree algorithms when the step is recorded once and replayed (what the CLI's default and
 --csv-total modes do), galaxy, theta 0.5 — the octree with every build form (nbody_octree_set_build).
-    python tools/time_step_graph.py [float]"""
+    python tools/time_step_graph.py [float]      (STEP_GRAPH_N=1000,2048: other sizes)"""
 import os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
-from conftest import load_package
-nb = load_package()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
+nb = load_package(experiments=bool(os.environ.get("STEP_GRAPH_EXP")))   # STEP_GRAPH_EXP=1: the experiments build (reads the NBODY_* switches)
 dtype = nb.F32 if (len(sys.argv) > 1 and sys.argv[1] == "float") else nb.F64
 
 
@@ -25,7 +25,7 @@ def per_step(dev, step, steps=200):
     return best
 
 
-for n in (10000, 100000, 1000000):
+for n in [int(v) for v in os.environ.get("STEP_GRAPH_N", "10000,100000,1000000").split(",")]:
     row = []
     for form in (1, 3):
         dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))

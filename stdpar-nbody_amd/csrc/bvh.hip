@@ -507,11 +507,8 @@ __device__ __forceinline__ uint32_t xcd_contiguous_block(uint32_t b, uint32_t nb
 // test -> next entry) is the serial chain, the accepted term's arithmetic is not, so each iteration decides,
 // requests the next record, and only then accumulates the current one.
 template <typename T, int D, bool COUNT>
-__global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
-                                                       T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
-                                                       uint32_t nlevels, uint32_t* __restrict__ counters) {
-  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  if (local >= count) return;
+__device__ __forceinline__ void bvh_walk_lane(const tree_rec<T>* node, uint32_t local, T* __restrict__ a, const T* __restrict__ x, T c,
+                                              uint32_t sz, uint32_t first, T theta2, uint32_t nlevels, uint32_t* __restrict__ counters) {
   const uint32_t i = first + local;
   const pair_consts<T> pc;
   T xs[D], acc[D];
@@ -579,6 +576,40 @@ __global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __rest
     counters[uint64_t(i) * 4 + 2] = c_mono;
     counters[uint64_t(i) * 4 + 3] = c_body;
   }
+}
+
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(64) void bvh_force_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a, const T* __restrict__ x,
+                                                       T c, uint32_t sz, uint32_t first, uint32_t count, T theta2,
+                                                       uint32_t nlevels, uint32_t* __restrict__ counters) {
+  const uint32_t local = xcd_contiguous_block(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  if (local >= count) return;
+  bvh_walk_lane<T, D, COUNT>(node, local, a, x, c, sz, first, theta2, nlevels, counters);
+}
+
+// Float trees that fit LDS (all records, bodies included, 32 bytes each: up to 2048 bodies — the reference's default run is 1000):
+// every block copies the tree into its LDS and its lanes walk it there; same arithmetic, same bits.  Measured at n = 1000
+// (profiles/r04/tiny_trees_kernel_stats.txt): 75 -> 53 us in float — the walk is a chain of dependent record fetches, but the
+// decision's own arithmetic is most of an iteration — and 128 -> 180 us in double (64-byte records: the lanes' four 16-byte
+// reads land on 4 of the 16 bank groups), so double keeps the walk over global memory.
+constexpr int kTreeLdsThreads    = 256;
+constexpr uint32_t kTreeLdsBytes = 144u << 10;  // of the CU's 160 KB
+template <typename T, int D, bool COUNT>
+__global__ __launch_bounds__(kTreeLdsThreads) void bvh_force_lds_kernel(const tree_rec<T>* __restrict__ node, uint32_t nrec, T* __restrict__ a,
+                                                                        const T* __restrict__ x, T c, uint32_t sz, uint32_t first,
+                                                                        uint32_t count, T theta2, uint32_t nlevels,
+                                                                        uint32_t* __restrict__ counters) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bvh_tree_lds[];
+  {
+    const uint4* src   = reinterpret_cast<const uint4*>(node);
+    uint4* dst         = reinterpret_cast<uint4*>(bvh_tree_lds);
+    const uint32_t n16 = nrec * uint32_t(sizeof(tree_rec<T>) / 16);
+    for (uint32_t q = threadIdx.x; q < n16; q += kTreeLdsThreads) dst[q] = src[q];
+  }
+  __syncthreads();
+  const uint32_t local = blockIdx.x * kTreeLdsThreads + threadIdx.x;
+  if (local >= count) return;
+  bvh_walk_lane<T, D, COUNT>(reinterpret_cast<const tree_rec<T>*>(bvh_tree_lds), local, a, x, c, sz, first, theta2, nlevels, counters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1269,8 +1300,25 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
     else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_IARGS);
 #undef NB_IARGS
   } else {
-    if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
-    else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
+    bool in_lds = false;
+    if constexpr (sizeof(T) == 4) {  // (nbody_bvh_set_traversal(t, 1) keeps the walk over global memory: the tests compare the two bit for bit)
+      const uint32_t nrec = t->nnodes + (1u << t->nlevels);
+      if (traversal == 0 && uint64_t(nrec) * sizeof(tree_rec<T>) <= kTreeLdsBytes) {
+        const uint32_t lblocks = (s->count + kTreeLdsThreads - 1) / kTreeLdsThreads;
+        const uint32_t bytes   = nrec * uint32_t(sizeof(tree_rec<T>));
+#define NB_LARGS                                                                                                              \
+  dim3(lblocks), dim3(kTreeLdsThreads), bytes, st, node, nrec, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), \
+   s->sz, s->first, s->count, th2, t->nlevels, t->counters
+        if (t->counters_on) hipLaunchKernelGGL((bvh_force_lds_kernel<T, D, true>), NB_LARGS);
+        else hipLaunchKernelGGL((bvh_force_lds_kernel<T, D, false>), NB_LARGS);
+#undef NB_LARGS
+        in_lds = true;
+      }
+    }
+    if (!in_lds) {
+      if (t->counters_on) hipLaunchKernelGGL((bvh_force_kernel<T, D, true>), NB_ARGS);
+      else hipLaunchKernelGGL((bvh_force_kernel<T, D, false>), NB_ARGS);
+    }
   }
 #undef NB_ARGS
 #undef NB_WARGS
@@ -1342,6 +1390,19 @@ extern "C" int nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t
   NB_ALLOC(t->order, sizeof(uint32_t) * (((size_t(n) + 63) / 64 / 8 + 1) * 2 + 8) * 8);  // 8 x (longest range + the largest budget)
   NB_ALLOC(t->order_n, sizeof(uint32_t) * 8);
 #undef NB_ALLOC
+  if (dtype == NBODY_F32 && (uint64_t(t->nnodes) + nleafs) * t->rec_bytes <= kTreeLdsBytes) {  // bvh_force_lds_kernel asks for more dynamic LDS than a kernel gets unasked
+    hipError_t e = hipSuccess;
+    auto allow   = [&](const void* f) {
+      if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, int(kTreeLdsBytes));
+    };
+#define NB_ALLOW(T, DD)                                                                  \
+  allow(reinterpret_cast<const void*>(&bvh_force_lds_kernel<T, DD, false>)); \
+  allow(reinterpret_cast<const void*>(&bvh_force_lds_kernel<T, DD, true>))
+    if (dim == 2) { NB_ALLOW(float, 2); }
+    if (dim == 3) { NB_ALLOW(float, 3); }
+#undef NB_ALLOW
+    if (e != hipSuccess) return fail(e, "hipFuncSetAttribute(bvh_force_lds_kernel)");
+  }
   *out = t;
   return NBODY_OK;
 }

@@ -109,13 +109,16 @@ def test_bvh_randomized_systems_bit_exact(nb, oracle):
 
 @pytest.mark.parametrize("dtype", [1, 0])
 def test_wave_cooperative_equals_per_lane_bitwise(nb, dtype):
-    """K9's two scheduling forms perform the same per-lane arithmetic in the same order."""
-    # the last two: theta so large that bodies accept the ROOT, at sizes that are powers of two (the sweep's end key)
+    """K9's scheduling forms perform the same per-lane arithmetic in the same order."""
+    # theta so large that bodies accept the ROOT, at sizes that are powers of two (the sweep's end key); the sizes around 2048:
+    # a float tree of up to 2048 bodies is walked from LDS by the auto form (bvh_force_lds_kernel)
     for dim, wl, n, theta in ((3, "galaxy", 20000, 0.5), (2, "uniform", 5001, 0.3), (3, "uniform", 777, 0.0), (3, "galaxy", 64, 1.0),
-                              (3, "uniform", 4096, 3.0), (2, "galaxy", 64, 2.5)):
+                              (3, "uniform", 4096, 3.0), (2, "galaxy", 64, 2.5), (3, "galaxy", 1000, 0.5), (2, "uniform", 2048, 0.4),
+                              (3, "uniform", 2049, 0.5), (3, "uniform", 2, 0.5), (2, "uniform", 3, 0.5)):
         res = []
-        # per-lane walks (the reference's loop and its product form of the opening test); the sweep (ISA, one-compare opening test)
-        for mode in (1, 5):
+        # per-lane walks over global memory (the reference's loop and its product form of the opening test); the sweep (ISA,
+        # one-compare opening test); auto (small float trees: the per-lane walk over a copy of the tree in LDS)
+        for mode in (1, 5, 0):
             dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, wl, n))
             dev.bvh.set_traversal(mode)
             dev.bvh.enable_counters(True)

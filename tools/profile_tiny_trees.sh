@@ -6,7 +6,7 @@ O=$R/gpurun_out/${1:-r04}
 mkdir -p $O
 S=210
 : > $O/tiny_trees_kernel_stats.txt
-for cfg in "octree 1000 float" "octree 2048 float" "octree 1000 double"; do
+for cfg in "octree 1000 float" "octree 2048 float" "octree 1000 double" "bvh 1000 float" "bvh 1000 double"; do
   set -- $cfg
   tag=$1_$2_$3
   rm -rf $O/trace_$tag

@@ -77,6 +77,26 @@ def test_octree_small_systems_one_block_step(nb, oracle, dtype, dim):
             assert maxrel(acc[-1], ref.a) <= FORCE_TOL[dtype] or n == 1, (wl, n, form)
             dev.close()
         assert np.array_equal(acc[0], acc[1]), (wl, n)
+    if dim == 3:
+        # 1300 bodies, 300 of them 2^-7 beside another one: 1094 cells — the insert goes the large path, the monopoles are still one
+        # block's (at most 3 rank chunks), and in float that block must take its chunk-by-chunk form (more cells than its 1024 threads)
+        rng = np.random.default_rng(3)
+        n, t = 1300, (np.float64 if dtype == 1 else np.float32)
+        x = rng.uniform(-1, 1, (n, 3)).astype(np.float32)
+        x[1:600:2] = x[0:600:2] + np.float32(2.0 ** -7)
+        hs, ref = nb.HostSystem(dtype, dim, n), oracle.State(dtype, dim, n)
+        hs.x[:], hs.m[:], hs.c, hs.dt = x.astype(t), 1.0, 1.0, 1e-3
+        ref.x[:], ref.m[:], ref.c, ref.dt = hs.x, hs.m, hs.c, hs.dt
+        ocnt, osize, omass = oracle.octree_step_force(ref, 0.5, want_counts=True)
+        assert 1024 < (osize - 1) // 8 <= n
+        dev = nb.DeviceSystem.from_host(hs)
+        dev.octree.enable_counters(True)
+        dev.octree_force(0.5)
+        dev.sync()
+        assert dev.octree.info(dev.stream) == (osize, omass)
+        assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt)
+        assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[dtype]
+        dev.close()
     for n in (1000, 1024):
         out = []
         for form in (3, 1):

@@ -1035,29 +1035,19 @@ __global__ __launch_bounds__(kSmallB) void ot_insert_small_kernel(ot_lcp_args<T,
   __shared__ uint32_t zero[kSmallN / kLcpB + 1];
   const uint32_t n = g.n, t = threadIdx.x;
   OT_SMALL_STAMP(0);
-  constexpr int E = kSmallN / kSmallB;
-  uint64_t key[E];
-  uint32_t pos[E];
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const uint32_t i = t * E + e;
-    key[e]           = i < n ? ot_path_key<T, D>(g.x, i, root) : ~0ull;
-    pos[e]           = i < n ? i : ~0u;
-  }
+  static_assert(kSmallN == uint32_t(kSmallB), "one pair per thread");
+  uint64_t key[1] = {t < n ? ot_path_key<T, D>(g.x, t, root) : ~0ull};
+  uint32_t pos[1] = {t < n ? t : ~0u};
   if (t <= uint32_t(ML)) hist[t] = 0;
   if (t < kSmallN / kLcpB + 1) zero[t] = 0;
   OT_SMALL_STAMP(1);
-  uint32_t P = E;
+  uint32_t P = 1;
   while (P < n) P <<= 1;
-  bitonic_sort_regs<kSmallB, E>(key, pos, P, K, V);
-  __syncthreads();  // (K / V may have carried a crossing stage)
-#pragma unroll
-  for (int e = 0; e < E; ++e) {
-    const uint32_t i = t * E + e;
-    if (i < n) {
-      K[i] = key[e], V[i] = pos[e];
-      skeys[i] = key[e], sidx[i] = pos[e];
-    }
+  block_sort_regs<kSmallB, 1>(key, pos, P, K, V);
+  __syncthreads();  // (K / V may have carried a merge round)
+  if (t < n) {
+    K[t] = key[0], V[t] = pos[0];
+    skeys[t] = key[0], sidx[t] = pos[0];
   }
   __syncthreads();
   OT_SMALL_STAMP(2);

@@ -1,17 +1,16 @@
 // Sort of (u64 key, u32 index) pairs by (key, original position) — shared by the Hilbert BVH (K6, replaces std::sort at
 // src/bvh.h:55-94) and the octree build.  The order is total (positions are distinct), so every correct sort produces the same
 // permutation bit for bit; three forms, by size:
-//   * n <= 2048: one block, a bitonic network over pairs held in registers (bitonic_sort_one_block_kernel);
+//   * n <= 2048: one block, the pairs held in registers: a network per wave, then merge rounds (sort_one_block_kernel, block_sort_regs);
 //   * up to 1.5 M pairs: a SPLITTER sort in five launches (round 4; 24 before): B - 1 splitters from a regular sample of the input
 //     sorted by one block, one counting pass + row scan + scatter into the B buckets (the "digit" of a pair is its bucket), then
-//     every bucket sorted by one block (a bitonic network over pairs held in registers).  Buckets follow the data's own quantiles, so clustered keys (a galaxy inside a box
+//     every bucket sorted by one block (block_sort_regs).  Buckets follow the data's own quantiles, so clustered keys (a galaxy inside a box
 //     inflated by escapers: most keys share their top 30 bits) cost nothing extra, and ties are broken by position, so equal keys
 //     cannot overfill a bucket;
 //   * beyond: stable LSD radix sort, 8 bits per pass (per-block digit histogram, per-digit row scan, stable scatter by wave
 //     match-any ranking with the 256-digit base scan folded in): 24 launches.
 // Kernels are `static` so both translation units can include this header.
 #pragma once
-#include <type_traits>
 #include "common.hpp"
 
 namespace nbody {
@@ -228,59 +227,50 @@ __device__ __forceinline__ bool pair_less_chain(uint64_t ka, uint32_t ia, uint64
   return __builtin_amdgcn_inverse_ballot_w64(mask);
 }
 
-// Bitonic sorting network with the pairs in REGISTERS: thread t of NT holds the elements t E ... t E + E - 1 of p[0 .. NT E) and
-// the aligned block p[0 .. P) comes out ascending (P a power of two, E <= P <= NT E; elements that are not there are
-// (~0, ~0): greater than every pair).  Of the log P (log P + 1) / 2 stages, those whose partner is in the same thread are
-// compare-exchanges between registers, those whose partner is in the same wave move the partner's pair through
-// ds_bpermute (no LDS storage, no barrier), and only the stages that cross waves (distance >= 64 E) go through LDS behind
-// block barriers: P = 4096 with 1024 threads: 10 of 78.  Measured against the same network with the pairs in LDS (a barrier or
-// a wave fence per stage), round 4: the 4096 sample pairs 53 -> 42 us, the 1000 pairs of the one-block octree insert 14.9 -> 12.8,
-// the bucket kernel 72 -> 68 (N = 10^6) and 24.6 -> 22.7 (10^5).  Either form is a chain of log P (log P + 1) / 2 dependent
-// stages of ~0.2 us (a ds_bpermute or LDS round trip, the compare, the selects): the stage count, not the traffic, is the time.
-// Ks / Vs: NT E pairs of LDS for the crossing stages.  Every thread of the block must call (block barriers inside).
+// (ka, ia) < (kb, ib), or <= where `or_equal`: the same chain started with a borrow (a - b - 1 < 0  <=>  a <= b; nothing overflows,
+// the chain IS the extended subtraction).  `or_equal_mask` = the lanes that ask for <=, as a lane mask.
+__device__ __forceinline__ bool pair_less_chain_or_equal(uint64_t ka, uint32_t ia, uint64_t kb, uint32_t ib, uint64_t or_equal_mask) {
+  uint64_t mask;
+  uint32_t t;
+  asm("s_mov_b64 vcc, %8\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %2, %3, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %4, %5, vcc\n\t"
+      "s_nop 1\n\t"
+      "v_subb_co_u32_e32 %1, vcc, %6, %7, vcc\n\t"
+      "s_mov_b64 %0, vcc"
+      : "=s"(mask), "=&v"(t)
+      : "v"(ia), "v"(ib), "v"(uint32_t(ka)), "v"(uint32_t(kb)), "v"(uint32_t(ka >> 32)), "v"(uint32_t(kb >> 32)), "s"(or_equal_mask)
+      : "vcc");
+  return __builtin_amdgcn_inverse_ballot_w64(mask);
+}
+
+// Sort of up to NT E pairs by one block, the pairs in REGISTERS: register e of thread t is element e NT + t of p[0 .. NT E), and the
+// aligned block p[0 .. P) comes out ascending (P a power of two <= NT E; elements that are not there are (~0, ~0): greater than
+// every pair).
+//   1. Every wave sorts the 64 pairs each of its registers holds across the lanes with a bitonic network — 21 stages, the partner's
+//      pair fetched with three ds_bpermute (no LDS storage, no barrier), the E networks of a thread side by side.
+//   2. The sorted runs are merged pairwise, log2(P / 64) rounds: every pair finds its rank in the sibling run by binary search in
+//      LDS (a pair of the left run goes before an equal one of the right run, so the padding cannot collide), and is written to
+//      its place in the merged run: log2(L) + 1 dependent LDS reads per round.
+// A sorting network over all P pairs is log P (log P + 1) / 2 dependent stages of ~0.2 us each whatever they move, so the stage
+// count is the time; this form has 21 + log2(P / 64) rounds of log2(L) + 1 probes.  Measured, round 4 (LDS network with a barrier
+// or a wave fence per stage / register network with LDS only across waves / this form): 1000 pairs of the one-block octree insert
+// 14.9 / 12.8 / 7.5 us; the 1024 sample pairs at N = 10^5 16 / 16 / 8.6; 2048 pairs - / 22 / 16.5; the 4096 sample pairs at 10^6
+// 53 / 43 / 38 — there the rounds are bound by LDS throughput (4096 x 12 probes of 12 bytes at random addresses per round); the
+// bucket kernel 72 / 67 / 69 at 10^6 (its duration is its largest bucket's), 24.6 / 22.7 / 20.2 at 10^5.
+// Ks / Vs: P pairs of LDS.  Every thread of the block must call (block barriers inside).
 template <int NT, int E>
-__device__ __forceinline__ void bitonic_sort_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint32_t P, uint64_t* Ks, uint32_t* Vs) {
+__device__ __forceinline__ void block_sort_regs(uint64_t (&k)[E], uint32_t (&v)[E], uint32_t P, uint64_t* Ks, uint32_t* Vs) {
+  // P == NT E, or E == 1 and P <= NT (block_sort_dispatch below picks E): every register of every wave below P takes part
   const uint32_t t = threadIdx.x, lane = t & 63u;
-  auto exchange = [&](int a, int b, bool asc) {  // (a, b) ascending if asc, descending if not
-    const bool sw    = pair_less_chain(k[b], v[b], k[a], v[a]) == asc;
-    const uint64_t x = k[a];
-    const uint32_t y = v[a];
-    k[a] = sw ? k[b] : x, v[a] = sw ? v[b] : y;
-    k[b] = sw ? x : k[b], v[b] = sw ? y : v[b];
-  };
-#pragma unroll
-  for (int kk = 2; kk <= E; kk <<= 1) {
-#pragma unroll
-    for (int j = kk >> 1; j >= 1; j >>= 1) {
-#pragma unroll
-      for (int e = 0; e < E; ++e)
-        if ((e & j) == 0) exchange(e, e | j, ((t * E + e) & uint32_t(kk)) == 0);
-    }
-  }
-  const bool active = (t & ~63u) * E < P;  // the wave holds elements of the block
-  for (uint32_t kk = 2 * E; kk <= P; kk <<= 1) {
-    const bool asc = ((t * E) & kk) == 0;
-    for (uint32_t j = kk >> 1; j >= uint32_t(E); j >>= 1) {
-      const uint32_t s    = j / E;                 // the partner is thread t ^ s, same register
-      const bool keep_min = ((t & s) == 0) == asc;
-      if (s >= 64u) {
-        if (active) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) Ks[e * NT + t] = k[e], Vs[e * NT + t] = v[e];
-        }
-        __syncthreads();
-        if (active) {
-#pragma unroll
-          for (int e = 0; e < E; ++e) {
-            const uint64_t pk = Ks[e * NT + (t ^ s)];
-            const uint32_t pv = Vs[e * NT + (t ^ s)];
-            const bool take   = pair_less_chain(pk, pv, k[e], v[e]) == keep_min;
-            k[e] = take ? pk : k[e], v[e] = take ? pv : v[e];
-          }
-        }
-        __syncthreads();
-      } else if (active) {
-        const int src = int((lane ^ s) << 2);
+  const bool holds = (t & ~63u) < P;  // (wave-uniform; false only where P < NT)
+  if (holds) {
+    for (uint32_t kk = 2; kk <= 64u; kk <<= 1) {
+      const bool asc = (lane & kk) == 0;  // (the last level: everywhere)
+      for (uint32_t j = kk >> 1; j >= 1u; j >>= 1) {
+        const bool keep_min = ((lane & j) == 0) == asc;
+        const int src       = int((lane ^ j) << 2);
 #pragma unroll
         for (int e = 0; e < E; ++e) {
           const uint32_t pl = uint32_t(__builtin_amdgcn_ds_bpermute(src, int(uint32_t(k[e]))));
@@ -292,46 +282,95 @@ __device__ __forceinline__ void bitonic_sort_regs(uint64_t (&k)[E], uint32_t (&v
         }
       }
     }
-    if (active) {
+  }
+  if (P <= 64u) return;
+  if (holds) {
 #pragma unroll
-      for (int j = E >> 1; j >= 1; j >>= 1) {
+    for (int e = 0; e < E; ++e) Ks[e * NT + t] = k[e], Vs[e * NT + t] = v[e];
+  }
+  __syncthreads();
+  for (uint32_t L = 64u; L < P; L <<= 1) {  // runs of L -> runs of 2 L
+    uint32_t c[E], sib[E];
+    uint64_t right[E];
+    if (holds) {
 #pragma unroll
-        for (int e = 0; e < E; ++e)
-          if ((e & j) == 0) exchange(e, e | j, asc);
+      for (int e = 0; e < E; ++e) {
+        const uint32_t run = (uint32_t(e) * NT + t) / L;  // (a wave's 64 pairs lie in one run)
+        sib[e]             = (run ^ 1u) * L;
+        right[e]           = __builtin_amdgcn_ballot_w64((run & 1u) != 0);
+        c[e]               = 0;
       }
+      // the sibling's pairs that go before this one: those < it (it is of the left run), those <= it (of the right run); the E
+      // searches of a thread advance together (each probe is a dependent LDS round trip)
+      for (uint32_t step = L >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          const uint32_t j = sib[e] + c[e] + step - 1;
+          if (pair_less_chain_or_equal(Ks[j], Vs[j], k[e], v[e], right[e])) c[e] += step;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t j = sib[e] + c[e];
+        c[e] += pair_less_chain_or_equal(Ks[j], Vs[j], k[e], v[e], right[e]);
+      }
+    }
+    __syncthreads();
+    if (holds) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        const uint32_t pos = uint32_t(e) * NT + t, run = pos / L;
+        const uint32_t dst = (run & ~1u) * L + pos % L + c[e];
+        Ks[dst] = k[e], Vs[dst] = v[e];
+      }
+    }
+    __syncthreads();
+    if (holds) {
+#pragma unroll
+      for (int e = 0; e < E; ++e) k[e] = Ks[e * NT + t], v[e] = Vs[e * NT + t];
     }
   }
 }
 
-// A sort that fits ONE block (n <= 2048: the reference's default run is 1000 bodies): the network above over one or two pairs per
-// thread, from (k0, position) into (k1, i1).  (Until round 4 all eight passes of the LSD radix sort in one launch: 44.6 us at
-// n = 2048 against 22 for the network; 16 dependent launches before that.)
+// the same for any power of two P <= NT EMAX: with as few registers per thread as P needs (the others hold padding only)
+template <int NT, int EMAX>
+__device__ __forceinline__ void block_sort_dispatch(uint64_t (&k)[EMAX], uint32_t (&v)[EMAX], uint32_t P, uint64_t* Ks, uint32_t* Vs) {
+  if constexpr (EMAX == 1) {
+    block_sort_regs<NT, 1>(k, v, P, Ks, Vs);
+  } else {
+    if (P <= uint32_t(NT) * (EMAX / 2)) {
+      block_sort_dispatch<NT, EMAX / 2>(reinterpret_cast<uint64_t(&)[EMAX / 2]>(k), reinterpret_cast<uint32_t(&)[EMAX / 2]>(v), P, Ks, Vs);
+    } else {
+      block_sort_regs<NT, EMAX>(k, v, P, Ks, Vs);
+    }
+  }
+}
+
+// A sort that fits ONE block (n <= 2048: the reference's default run is 1000 bodies): the block sort above over one or two pairs
+// per thread, from (k0, position) into (k1, i1).  (Until round 4 all eight passes of the LSD radix sort in one launch: 44.6 us at
+// n = 2048; 16 dependent launches before that.)
 constexpr int kOneBlockThreads = 1024;
-static __global__ __launch_bounds__(kOneBlockThreads) void bitonic_sort_one_block_kernel(const uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
+static __global__ __launch_bounds__(kOneBlockThreads) void sort_one_block_kernel(const uint64_t* __restrict__ k0, uint64_t* __restrict__ k1,
                                                                                          uint32_t* __restrict__ i1, uint32_t n) {
-  __shared__ uint64_t K[2 * kOneBlockThreads];
-  __shared__ uint32_t V[2 * kOneBlockThreads];
-  auto sort_with = [&](auto width) {
-    constexpr int E = decltype(width)::value;
-    uint64_t k[E];
-    uint32_t v[E];
+  constexpr int E = 2;
+  __shared__ uint64_t K[E * kOneBlockThreads];
+  __shared__ uint32_t V[E * kOneBlockThreads];
+  uint64_t k[E];
+  uint32_t v[E];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t q = threadIdx.x * E + e;
-      k[e]             = q < n ? k0[q] : ~0ull;
-      v[e]             = q < n ? q : ~0u;
-    }
-    uint32_t P = E;
-    while (P < n) P <<= 1;
-    bitonic_sort_regs<kOneBlockThreads, E>(k, v, P, K, V);
+  for (int e = 0; e < E; ++e) {
+    const uint32_t q = e * kOneBlockThreads + threadIdx.x;
+    k[e]             = q < n ? k0[q] : ~0ull;
+    v[e]             = q < n ? q : ~0u;
+  }
+  uint32_t P = 1;
+  while (P < n) P <<= 1;
+  block_sort_dispatch<kOneBlockThreads, E>(k, v, P, K, V);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      const uint32_t q = threadIdx.x * E + e;
-      if (q < n) k1[q] = k[e], i1[q] = v[e];
-    }
-  };
-  if (n <= uint32_t(kOneBlockThreads)) sort_with(std::integral_constant<int, 1>{});
-  else sort_with(std::integral_constant<int, 2>{});
+  for (int e = 0; e < E; ++e) {
+    const uint32_t q = e * kOneBlockThreads + threadIdx.x;
+    if (q < n) k1[q] = k[e], i1[q] = v[e];
+  }
 }
 
 // S1: the splitters.  One block sorts m = splitter_sample(B) pairs taken at a regular stride from the input and keeps every
@@ -349,15 +388,15 @@ static __global__ __launch_bounds__(kSampleThreads) void splitter_sample_kernel(
   uint32_t v[E];
 #pragma unroll
   for (int e = 0; e < E; ++e) {
-    const uint32_t q = threadIdx.x * E + e;
+    const uint32_t q = e * kSampleThreads + threadIdx.x;
     const uint32_t i = q < m ? uint32_t((uint64_t(q) * n + n / 2) / m) : 0u;  // < n
     k[e]             = q < m ? keys[i] : ~0ull;
     v[e]             = q < m ? i : ~0u;
   }
-  bitonic_sort_regs<kSampleThreads, E>(k, v, m < uint32_t(E) ? uint32_t(E) : m, K, V);
+  block_sort_dispatch<kSampleThreads, E>(k, v, m, K, V);
 #pragma unroll
   for (int e = 0; e < E; ++e) {  // bucket b holds the pairs p with splitter[b-1] <= p < splitter[b]
-    const uint32_t q = threadIdx.x * E + e;
+    const uint32_t q = e * kSampleThreads + threadIdx.x;
     if (q < m && q >= every && q % every == 0) {
       split_key[q / every - 1] = k[e];
       split_idx[q / every - 1] = v[e];
@@ -474,7 +513,7 @@ static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const u
   }
 }
 
-// S5: one block per bucket sorts it — in registers up to kBucketCap pairs (2, 4 or 8 per thread by the bucket's size), in place in
+// S5: one block per bucket sorts it — in registers up to kBucketCap pairs, in place in
 // global memory beyond (a bucket that large takes an input whose regular sample misrepresents it; correct, slow) — and writes it
 // to the output buffers at the same positions.  (One block per bucket, not a loop over buckets in fewer blocks: 256 ... 2048 blocks
 // for 2048 buckets time the same.)
@@ -489,27 +528,22 @@ static __global__ __launch_bounds__(kBucketThreads) void splitter_bucket_sort_ke
   if (cnt == 0) return;
   uint32_t P = 1;
   while (P < cnt) P <<= 1;
-  if (cnt <= kBucketCap) {  // as few pairs per thread as the bucket allows: the network is a chain of dependent stages, and waves side by side hide it
-    auto sort_with = [&](auto width) {
-      constexpr int E = decltype(width)::value;
-      uint64_t k[E];
-      uint32_t v[E];
+  if (cnt <= kBucketCap) {
+    constexpr int E = kBucketCap / kBucketThreads;  // (the registers beyond the bucket's size take no part)
+    uint64_t k[E];
+    uint32_t v[E];
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t q = threadIdx.x * E + e;
-        k[e]             = q < cnt ? keys_in[start + q] : ~0ull;
-        v[e]             = q < cnt ? idx_in[start + q] : ~0u;
-      }
-      bitonic_sort_regs<kBucketThreads, E>(k, v, P < uint32_t(E) ? uint32_t(E) : P, K, V);
+    for (int e = 0; e < E; ++e) {
+      const uint32_t q = e * kBucketThreads + threadIdx.x;
+      k[e]             = q < cnt ? keys_in[start + q] : ~0ull;
+      v[e]             = q < cnt ? idx_in[start + q] : ~0u;
+    }
+    block_sort_dispatch<kBucketThreads, E>(k, v, P, K, V);
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t q = threadIdx.x * E + e;
-        if (q < cnt) keys_out[start + q] = k[e], idx_out[start + q] = v[e];
-      }
-    };
-    if (P <= 2u * kBucketThreads) sort_with(std::integral_constant<int, 2>{});
-    else if (P <= 4u * kBucketThreads) sort_with(std::integral_constant<int, 4>{});
-    else sort_with(std::integral_constant<int, int(kBucketCap / kBucketThreads)>{});
+    for (int e = 0; e < E; ++e) {
+      const uint32_t q = e * kBucketThreads + threadIdx.x;
+      if (q < cnt) keys_out[start + q] = k[e], idx_out[start + q] = v[e];
+    }
   } else {
     bitonic_sort_global<kBucketThreads>(keys_in + start, idx_in + start, P, cnt);
     for (uint32_t q = threadIdx.x; q < cnt; q += kBucketThreads) keys_out[start + q] = keys_in[start + q], idx_out[start + q] = idx_in[start + q];
@@ -546,7 +580,7 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
                             int* final_buf) {
   const uint32_t nblk    = radix_sort_blocks(n);
   if (nblk == 1) {
-    hipLaunchKernelGGL(bitonic_sort_one_block_kernel, dim3(1), dim3(kOneBlockThreads), 0, st, keys[0], keys[1], idx[1], n);
+    hipLaunchKernelGGL(sort_one_block_kernel, dim3(1), dim3(kOneBlockThreads), 0, st, keys[0], keys[1], idx[1], n);
     NB_HIP(hipGetLastError());
     *final_buf = 1;
     return NBODY_OK;

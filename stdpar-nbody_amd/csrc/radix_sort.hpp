@@ -250,9 +250,11 @@ __device__ __forceinline__ bool pair_less_chain_or_equal(uint64_t ka, uint32_t i
 // every pair).
 //   1. Every wave sorts the 64 pairs each of its registers holds across the lanes with a bitonic network — 21 stages, the partner's
 //      pair fetched with three ds_bpermute (no LDS storage, no barrier), the E networks of a thread side by side.
-//   2. The sorted runs are merged pairwise, log2(P / 64) rounds: every pair finds its rank in the sibling run by binary search in
-//      LDS (a pair of the left run goes before an equal one of the right run, so the padding cannot collide), and is written to
-//      its place in the merged run: log2(L) + 1 dependent LDS reads per round.
+//   2. The sorted runs are merged pairwise, log2(P / 64) rounds.  One pair per thread: every pair finds its rank in the sibling run
+//      by binary search in LDS and is written to its place in the merged run (log2(L) + 1 dependent LDS reads per round).  Several
+//      pairs per thread: every thread finds by one binary search where its stretch of the merged run starts in the two runs
+//      (the merge path) and merges its E pairs from there.  A pair of the left run goes before an equal one of the right run, so
+//      the padding cannot collide.
 // A sorting network over all P pairs is log P (log P + 1) / 2 dependent stages of ~0.2 us each whatever they move, so the stage
 // count is the time; this form has 21 + log2(P / 64) rounds of log2(L) + 1 probes.  Measured, round 4 (LDS network with a barrier
 // or a wave fence per stage / register network with LDS only across waves / this form): 1000 pairs of the one-block octree insert
@@ -289,46 +291,64 @@ __device__ __forceinline__ void block_sort_regs(uint64_t (&k)[E], uint32_t (&v)[
     for (int e = 0; e < E; ++e) Ks[e * NT + t] = k[e], Vs[e * NT + t] = v[e];
   }
   __syncthreads();
-  for (uint32_t L = 64u; L < P; L <<= 1) {  // runs of L -> runs of 2 L
-    uint32_t c[E], sib[E];
-    uint64_t right[E];
-    if (holds) {
+  if constexpr (E == 1) {
+    for (uint32_t L = 64u; L < P; L <<= 1) {  // runs of L -> runs of 2 L: every pair ranks itself in the sibling run
+      uint32_t c = 0;
+      if (holds) {
+        const uint32_t run   = t / L;  // (a wave's 64 pairs lie in one run)
+        const uint32_t sib   = (run ^ 1u) * L;
+        const uint64_t right = __builtin_amdgcn_ballot_w64((run & 1u) != 0);
+        // the sibling's pairs that go before this one: those < it (it is of the left run), those <= it (of the right run)
+        for (uint32_t step = L >> 1; step >= 1; step >>= 1)
+          if (pair_less_chain_or_equal(Ks[sib + c + step - 1], Vs[sib + c + step - 1], k[0], v[0], right)) c += step;
+        c += pair_less_chain_or_equal(Ks[sib + c], Vs[sib + c], k[0], v[0], right);
+      }
+      __syncthreads();
+      if (holds) {
+        const uint32_t dst = ((t / L) & ~1u) * L + t % L + c;
+        Ks[dst] = k[0], Vs[dst] = v[0];
+      }
+      __syncthreads();
+      if (holds) k[0] = Ks[t], v[0] = Vs[t];
+    }
+  } else {
+    // Several pairs per thread (P == NT E, every thread takes part): thread t produces the E consecutive pairs t E ... t E + E - 1 of
+    // the merged runs — it finds where that stretch starts in the two runs (the merge path: one binary search per THREAD, not per
+    // pair) and merges E steps from there; log2(L) + 2 E dependent LDS reads per round and thread instead of E (log2(L) + 1), which
+    // at 4096 pairs were the LDS's whole throughput.  A pair of the left run goes before an equal one of the right run.
+    for (uint32_t L = 64u; L < P; L <<= 1) {
+      const uint32_t o0 = t * E, pb = o0 & ~(2u * L - 1u), o = o0 - pb;  // (E divides 2 L: the stretch lies in one pair of runs)
+      const uint64_t *ak = Ks + pb, *bk = Ks + pb + L;
+      const uint32_t *av = Vs + pb, *bv = Vs + pb + L;
+      uint32_t lo = o > L ? o - L : 0u, hi = o < L ? o : L;  // pairs of the left run among the first o of the merged pair
+      while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (pair_less_chain(bk[o - 1u - mid], bv[o - 1u - mid], ak[mid], av[mid])) hi = mid;  // left[mid] comes after right[o-1-mid]
+        else lo = mid + 1u;
+      }
+      uint32_t i = lo, j = o - lo;
+      uint64_t ka = ak[i < L ? i : L - 1u], kb = bk[j < L ? j : L - 1u];
+      uint32_t va = av[i < L ? i : L - 1u], vb = bv[j < L ? j : L - 1u];
 #pragma unroll
       for (int e = 0; e < E; ++e) {
-        const uint32_t run = (uint32_t(e) * NT + t) / L;  // (a wave's 64 pairs lie in one run)
-        sib[e]             = (run ^ 1u) * L;
-        right[e]           = __builtin_amdgcn_ballot_w64((run & 1u) != 0);
-        c[e]               = 0;
-      }
-      // the sibling's pairs that go before this one: those < it (it is of the left run), those <= it (of the right run); the E
-      // searches of a thread advance together (each probe is a dependent LDS round trip)
-      for (uint32_t step = L >> 1; step >= 1; step >>= 1) {
-#pragma unroll
-        for (int e = 0; e < E; ++e) {
-          const uint32_t j = sib[e] + c[e] + step - 1;
-          if (pair_less_chain_or_equal(Ks[j], Vs[j], k[e], v[e], right[e])) c[e] += step;
+        const bool take_a = i < L && (j >= L || !pair_less_chain(kb, vb, ka, va));
+        k[e] = take_a ? ka : kb, v[e] = take_a ? va : vb;
+        i += take_a, j += !take_a;
+        if (e + 1 < E) {  // the next head of the run the pair came from
+          const uint32_t nx = take_a ? (i < L ? i : L - 1u) : L + (j < L ? j : L - 1u);
+          const uint64_t nk = ak[nx];
+          const uint32_t nv = av[nx];
+          ka = take_a ? nk : ka, va = take_a ? nv : va;
+          kb = take_a ? kb : nk, vb = take_a ? vb : nv;
         }
       }
+      __syncthreads();
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t j = sib[e] + c[e];
-        c[e] += pair_less_chain_or_equal(Ks[j], Vs[j], k[e], v[e], right[e]);
-      }
+      for (int e = 0; e < E; ++e) Ks[o0 + e] = k[e], Vs[o0 + e] = v[e];
+      __syncthreads();
     }
-    __syncthreads();
-    if (holds) {
 #pragma unroll
-      for (int e = 0; e < E; ++e) {
-        const uint32_t pos = uint32_t(e) * NT + t, run = pos / L;
-        const uint32_t dst = (run & ~1u) * L + pos % L + c[e];
-        Ks[dst] = k[e], Vs[dst] = v[e];
-      }
-    }
-    __syncthreads();
-    if (holds) {
-#pragma unroll
-      for (int e = 0; e < E; ++e) k[e] = Ks[e * NT + t], v[e] = Vs[e * NT + t];
-    }
+    for (int e = 0; e < E; ++e) k[e] = Ks[e * NT + t], v[e] = Vs[e * NT + t];
   }
 }
 
@@ -404,17 +424,6 @@ static __global__ __launch_bounds__(kSampleThreads) void splitter_sample_kernel(
   }
 }
 
-// bucket of a pair: the number of splitters <= it (splitters in LDS, B a power of two)
-__device__ __forceinline__ uint32_t bucket_of(const uint64_t* __restrict__ sk, const uint32_t* __restrict__ si, uint32_t B, uint64_t key,
-                                              uint32_t idx) {
-  uint32_t lo = 0;  // invariant: splitters [0, lo) are <= the pair, and the answer is < lo + step after each step
-  for (uint32_t step = B >> 1; step >= 1; step >>= 1) {
-    const uint32_t mid = lo + step;  // mid - 1 in [0, B - 2]
-    if (!pair_less(key, idx, sk[mid - 1], si[mid - 1])) lo = mid;
-  }
-  return lo;
-}
-
 // lanes of the wave holding the same bucket as this one (match-any over the log2(B) bits of the bucket number)
 __device__ __forceinline__ uint64_t same_bucket_lanes(uint32_t b, bool valid, int bits) {
   uint64_t same = __ballot(valid);
@@ -427,8 +436,8 @@ __device__ __forceinline__ uint64_t same_bucket_lanes(uint32_t b, bool valid, in
 }
 
 // S2: per-(bucket, block) counts; the bucket of every pair is kept (u16) for the scatter.
-template <int IPT>
-static __global__ __launch_bounds__(kSortB) void splitter_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
+template <int NT, int IPT>
+static __global__ __launch_bounds__(NT) void splitter_count_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
                                                                        const uint64_t* __restrict__ split_key,
                                                                        const uint32_t* __restrict__ split_idx,
                                                                        uint32_t* __restrict__ hist, uint32_t nblk,
@@ -437,30 +446,48 @@ static __global__ __launch_bounds__(kSortB) void splitter_count_kernel(const uin
   uint64_t* sk  = reinterpret_cast<uint64_t*>(smem);
   uint32_t* si  = reinterpret_cast<uint32_t*>(sk + B);
   uint32_t* cnt = si + B;
-  for (uint32_t q = threadIdx.x; q < B; q += kSortB) {
+  for (uint32_t q = threadIdx.x; q < B; q += NT) {
     if (q + 1 < B) sk[q] = split_key[q], si[q] = split_idx[q];
     cnt[q] = 0;
   }
   __syncthreads();
   const int lane = threadIdx.x & 63;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
+  // the thread's IPT searches advance together: each probe is a dependent LDS round trip (one after the other they were most of
+  // the kernel: 29 us at N = 10^6)
+  uint64_t key[IPT];
+  uint32_t lo[IPT];
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
-    const uint64_t i = uint64_t(blockIdx.x) * (kSortB * IPT) + q * kSortB + threadIdx.x;
+    const uint64_t i = uint64_t(blockIdx.x) * (NT * IPT) + q * NT + threadIdx.x;
+    key[q]           = i < n ? keys[i] : 0ull;
+    lo[q]            = 0;  // invariant: splitters [0, lo) are <= the pair, and the answer is < lo + step after each step
+  }
+  for (uint32_t step = B >> 1; step >= 1; step >>= 1) {
+#pragma unroll
+    for (int q = 0; q < IPT; ++q) {
+      const uint32_t i   = blockIdx.x * uint32_t(NT * IPT) + q * NT + threadIdx.x;
+      const uint32_t mid = lo[q] + step;  // mid - 1 in [0, B - 2]
+      if (!pair_less_chain(key[q], i, sk[mid - 1], si[mid - 1])) lo[q] = mid;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < IPT; ++q) {
+    const uint64_t i = uint64_t(blockIdx.x) * (NT * IPT) + q * NT + threadIdx.x;
     const bool valid = i < n;
-    const uint32_t b = valid ? bucket_of(sk, si, B, keys[i], uint32_t(i)) : 0u;
+    const uint32_t b = valid ? lo[q] : 0u;
     if (valid) bucket_out[i] = uint16_t(b);
     const uint64_t same = same_bucket_lanes(b, valid, bits);  // one LDS atomic per distinct bucket of the strip
     if (valid && (same & lt_mask) == 0ull) atomicAdd(&cnt[b], uint32_t(__popcll(same)));
   }
   __syncthreads();
-  for (uint32_t q = threadIdx.x; q < B; q += kSortB) hist[uint64_t(q) * nblk + blockIdx.x] = cnt[q];
+  for (uint32_t q = threadIdx.x; q < B; q += NT) hist[uint64_t(q) * nblk + blockIdx.x] = cnt[q];
 }
 
 // S4: scatter into the buckets (after radix_scan_rows_kernel over the B rows).  Order inside a bucket is whatever the LDS
 // atomics give: the bucket is sorted afterwards, and the sorted order is unique.
-template <int IPT>
-static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
+template <int NT, int IPT>
+static __global__ __launch_bounds__(NT) void splitter_scatter_kernel(const uint64_t* __restrict__ keys, uint32_t n, uint32_t B, int bits,
                                                                          const uint16_t* __restrict__ bucket_in,
                                                                          const uint32_t* __restrict__ hist,
                                                                          const uint32_t* __restrict__ totals, uint32_t nblk,
@@ -468,12 +495,12 @@ static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const u
                                                                          uint32_t* __restrict__ bucket_start) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint32_t* base = reinterpret_cast<uint32_t*>(smem);  // [B]: where this block's pairs of a bucket go next
-  __shared__ uint32_t wsum[kSortB / 64];
+  __shared__ uint32_t wsum[NT / 64];
   __shared__ uint32_t carry;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
-  for (uint32_t b0 = 0; b0 < B; b0 += kSortB) {  // exclusive scan of the bucket totals, kSortB at a time
+  for (uint32_t b0 = 0; b0 < B; b0 += NT) {  // exclusive scan of the bucket totals, NT at a time
     const uint32_t q = b0 + threadIdx.x;
     const uint32_t v = q < B ? totals[q] : 0u;
     uint32_t inc     = v;
@@ -491,14 +518,14 @@ static __global__ __launch_bounds__(kSortB) void splitter_scatter_kernel(const u
       if (blockIdx.x == 0) bucket_start[q] = pre + inc - v;
     }
     __syncthreads();
-    if (threadIdx.x == kSortB - 1) carry = pre + inc;
+    if (threadIdx.x == NT - 1) carry = pre + inc;
     __syncthreads();
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) bucket_start[B] = n;
   const uint64_t lt_mask = (1ull << lane) - 1ull;
 #pragma unroll
   for (int q = 0; q < IPT; ++q) {
-    const uint64_t i = uint64_t(blockIdx.x) * (kSortB * IPT) + q * kSortB + threadIdx.x;
+    const uint64_t i = uint64_t(blockIdx.x) * (NT * IPT) + q * NT + threadIdx.x;
     const bool valid = i < n;
     const uint32_t b = valid ? bucket_in[i] : 0u;
     const uint64_t same = same_bucket_lanes(b, valid, bits);
@@ -552,8 +579,13 @@ static __global__ __launch_bounds__(kBucketThreads) void splitter_bucket_sort_ke
 
 // Scratch of a sort of n pairs, in u32 words: the count matrix (rows x blocks) + row totals, the bucket starts, the splitters
 // and the per-pair bucket numbers.  hist must hold radix_sort_scratch_words(n) words.
-constexpr uint32_t kSplitSmallN = 1u << 18;  // up to here the counting / scatter blocks take 512 pairs (more, smaller blocks), beyond 2048
-inline uint32_t splitter_blocks(uint32_t n) { return n <= kSplitSmallN ? (n + 511u) / 512u : (n + kSortTile - 1) / kSortTile; }
+// pairs per counting / scatter block: 512 up to 2^18 pairs (256 threads x 2: more, smaller blocks), 2048 beyond (1024 threads x 2).
+// Measured at N = 10^6 (count / scatter, us): 256 threads x 8 pairs 29 / 35 (the thread's searches one after the other or together:
+// the same), x 4 29 / 40, x 16 33 / 45; 1024 threads x 2 (shipped) 21 / 31 — the per-block fixed work (24 KB of splitters in, 2048
+// counts out, the scan of the bucket totals) is what the larger block shortens.
+constexpr uint32_t kSplitSmallN = 1u << 18;
+constexpr int kSplitBigThreads  = 1024;
+inline uint32_t splitter_blocks(uint32_t n) { return n <= kSplitSmallN ? (n + 511u) / 512u : (n + 2047u) / 2048u; }
 inline size_t radix_sort_scratch_words(uint32_t n) {
   const bool split  = n > kSortTile && n <= kSplitterMaxN;
   const size_t nblk = split ? splitter_blocks(n) : (size_t(n) + kSortTile - 1) / kSortTile;
@@ -597,16 +629,16 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
     hipLaunchKernelGGL(splitter_sample_kernel, dim3(1), dim3(kSampleThreads), 0, st, keys[0], n, B, split_key, split_idx);
     NB_HIP(hipGetLastError());
     if (n <= kSplitSmallN)
-      hipLaunchKernelGGL(splitter_count_kernel<2>, dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
+      hipLaunchKernelGGL((splitter_count_kernel<kSortB, 2>), dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
     else
-      hipLaunchKernelGGL(splitter_count_kernel<kSortIPT>, dim3(sblk), dim3(kSortB), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
+      hipLaunchKernelGGL((splitter_count_kernel<kSplitBigThreads, 2>), dim3(sblk), dim3(kSplitBigThreads), B * 16u, st, keys[0], n, B, bits, split_key, split_idx, hist, sblk, bucket);
     NB_HIP(hipGetLastError());
     hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(B), dim3(kSortB), 0, st, hist, sblk, totals);
     NB_HIP(hipGetLastError());
     if (n <= kSplitSmallN)
-      hipLaunchKernelGGL(splitter_scatter_kernel<2>, dim3(sblk), dim3(kSortB), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
+      hipLaunchKernelGGL((splitter_scatter_kernel<kSortB, 2>), dim3(sblk), dim3(kSortB), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
     else
-      hipLaunchKernelGGL(splitter_scatter_kernel<kSortIPT>, dim3(sblk), dim3(kSortB), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
+      hipLaunchKernelGGL((splitter_scatter_kernel<kSplitBigThreads, 2>), dim3(sblk), dim3(kSplitBigThreads), B * 4u, st, keys[0], n, B, bits, bucket, hist, totals, sblk, keys[1], idx[1], bucket_start);
     NB_HIP(hipGetLastError());
     hipLaunchKernelGGL(splitter_bucket_sort_kernel, dim3(B), dim3(kBucketThreads), 0, st, keys[1], idx[1], keys[0], idx[0], bucket_start);
     NB_HIP(hipGetLastError());

@@ -763,7 +763,7 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
 //     `w2 < fl(theta^2 d2)` <=> `v < d2` bit for bit.  Bodies carry v = -1 (always accepted); a NaN distance accepts, as
 //     before, so no walk can descend below the body level whatever the state holds.  The per-lane form keeps the reference's
 //     product; the tests hold the two forms equal decision by decision;
-//   * two record blocks (s[64:79], s[80:95]) and two sets of position registers used in turn by two copies of the step: the
+//   * two record blocks (s[48:63], s[64:79]) and two sets of position registers used in turn by two copies of the step: the
 //     next record is requested into the other block as soon as the decision is made and the accepted term reads the mass
 //     straight from its own block (no copies), every successor is computed directly into the other set (no moves), the skip key
 //     `ka = cur + (span - 1) + "is a left child"` (one s_addc_u32) IS the other copy's `cur`;
@@ -963,17 +963,17 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
 #define K9_LOAD16(BLK, O) "s_load_dwordx16 " BLK ", %[node], %[off" O "]\n\t"
 #define K9_LOAD8(BLK, O) "s_load_dwordx8 " BLK ", %[node], %[off" O "]\n\t"
 
-// f64: A = s[64:79], B = s[80:95].  D = 3: x s[0:1] y s[2:3] z s[4:5] m s[6:7] w s[8:9] w2 s[10:11] v s[12:13] of the block;
+// f64: A = s[48:63], B = s[64:79] (the highest SGPR the kernel touches decides its waves per SIMD: see below).  D = 3: x s[0:1] y s[2:3] z s[4:5] m s[6:7] w s[8:9] w2 s[10:11] v s[12:13] of the block;
 // D = 2: x s[0:1] y s[2:3] m s[4:5] w s[6:7] w2 s[8:9] v s[10:11].
 #define K9_PROGRAM_F64(Z, AX, AY, AZ, AM, AV, AVHI, BX, BY, BZ, BM, BV, BVHI, CNT_A, CNT_B)                               \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
-  K9_LOAD16("s[64:79]", "A")                                                                                              \
-  K9_STEP("A", "B", "6", "64", K9_LOAD16("s[80:95]", "B"), CNT_A, K9_TEST_F64(Z, AX, AY, AZ, AV),                         \
+  K9_LOAD16("s[48:63]", "A")                                                                                              \
+  K9_STEP("A", "B", "6", "64", K9_LOAD16("s[64:79]", "B"), CNT_A, K9_TEST_F64(Z, AX, AY, AZ, AV),                         \
           K9_EVAL_F64("Ad", Z, AM, AVHI, CNT_B), "")                                                                    \
-  K9_STEP("B", "A", "6", "64", K9_LOAD16("s[64:79]", "A"), CNT_A, K9_TEST_F64(Z, BX, BY, BZ, BV),                         \
+  K9_STEP("B", "A", "6", "64", K9_LOAD16("s[48:63]", "A"), CNT_A, K9_TEST_F64(Z, BX, BY, BZ, BV),                         \
           K9_EVAL_F64("Bd", Z, BM, BVHI, CNT_B), "s_branch .LK9topA%=\n")                                               \
-  K9_SKIP("A", "B", "6", "64", "6", K9_LOAD16("s[80:95]", "B"), K9_EVAL_F64("As", Z, AM, AVHI, CNT_B))                    \
-  K9_SKIP("B", "A", "6", "64", "6", K9_LOAD16("s[64:79]", "A"), K9_EVAL_F64("Bs", Z, BM, BVHI, CNT_B))                    \
+  K9_SKIP("A", "B", "6", "64", "6", K9_LOAD16("s[64:79]", "B"), K9_EVAL_F64("As", Z, AM, AVHI, CNT_B))                    \
+  K9_SKIP("B", "A", "6", "64", "6", K9_LOAD16("s[48:63]", "A"), K9_EVAL_F64("Bs", Z, BM, BVHI, CNT_B))                    \
   K9_NEAR_F64("Ad", Z, AM) K9_NEAR_F64("As", Z, AM) K9_NEAR_F64("Bd", Z, BM) K9_NEAR_F64("Bs", Z, BM)                     \
   ".LK9end%=:\n\t"                                                                                                        \
   "s_waitcnt lgkmcnt(0)\n\t" /* a record requested past the end of the walk: it must land before the registers are reused */ \
@@ -1050,11 +1050,15 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi),                  \
     [k0375] "s"(k0375), [m52] "s"(m52), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
     [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
-  : K9_CLOBBER8, "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95"
+  : "vcc", "scc", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",  \
+    "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
+    // The record blocks sit at s[48:79], not at the top of the file: a gfx9-class SIMD has 800 SGPRs, allocated in 16s, so a wave
+    // that touches s80 or above (+ VCC and the reserved pairs: > 96) leaves room for 7 waves per SIMD, not 8.  Round 4's first form
+    // had them at s[64:95] (next free SGPR 104: seven waves).
 #define K9_REGS3                                                                                                           \
-  "s[64:65]", "s[66:67]", "s[68:69]", "s[70:71]", "s[76:77]", "s77", "s[80:81]", "s[82:83]", "s[84:85]", "s[86:87]", "s[92:93]", "s93"
+  "s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[60:61]", "s61", "s[64:65]", "s[66:67]", "s[68:69]", "s[70:71]", "s[76:77]", "s77"
 #define K9_REGS2                                                                                                           \
-  "s[64:65]", "s[66:67]", "", "s[68:69]", "s[74:75]", "s75", "s[80:81]", "s[82:83]", "", "s[84:85]", "s[90:91]", "s91"
+  "s[48:49]", "s[50:51]", "", "s[52:53]", "s[58:59]", "s59", "s[64:65]", "s[66:67]", "", "s[68:69]", "s[74:75]", "s75"
     if constexpr (D == 3) {
       if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
       else asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_NOCOUNT_A, "") K9_OPERANDS);

@@ -8,7 +8,7 @@ for f in bench_n1.json configs_all.json k1_times.json benchmark.log benchmark.cs
          pmc_k2_config3.txt pmc_k9_config4.txt energy_times.txt octree_times.txt step_graph.txt pmc_octree_walk_f32.txt \
          octree_times_walks.txt small_trees_kernel_stats.txt; do cp $S/$f $D/$f; done
 for f in bench_n1_kernel_stats.csv bench_n1_pmc_all_pairs_force.json bench_n1_under_rocprof.json; do cp $P/$f $D/$f; done
-cp $(find $S/trace_k2 -name "*kernel_stats.csv" | head -1) $D/config3_collapsed_kernel_stats.csv
-cp $(find $S/trace_k9 -name "*kernel_stats.csv" | head -1) $D/config4_bvh_kernel_stats.csv
-cp $(find $S/trace_energy -name "*kernel_stats.csv" | head -1) $D/energies_kernel_stats.csv
+cp $(ls -t $(find $S/trace_k2 -name "*kernel_stats.csv") | head -1) $D/config3_collapsed_kernel_stats.csv   # (the newest: gpurun_out/ keeps earlier sessions)
+cp $(ls -t $(find $S/trace_k9 -name "*kernel_stats.csv") | head -1) $D/config4_bvh_kernel_stats.csv
+cp $(ls -t $(find $S/trace_energy -name "*kernel_stats.csv") | head -1) $D/energies_kernel_stats.csv
 git status --short $D

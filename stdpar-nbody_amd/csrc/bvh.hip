@@ -1269,7 +1269,8 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   } else if (wave && bpl == 1 && t->sorted && t->final_buf == 0 && !plain) {
     // Work items (bvh_items_kernel): groups that straddle a jump of the key order are cut in two and started first.  Measured
     // in the CLI's step loop (ms per whole bvh step; index order / start order only / start order + cut): N = 10^6 8.05 / 7.4 /
-    // 7.4, 5*10^5 5.3 / 4.6 / 4.3.  The sorted keys are in keys[1] (8 radix passes end in the buffer they started from).
+    // 7.4, 5*10^5 5.3 / 4.6 / 4.3.  The sorted keys are in keys[1] when the sort ends in the buffer it started from
+    // (final_buf == 0: the splitter sort, the radix sort's 8 passes; not the one-block sort, whose small trees take finer work items instead).
     uint32_t den = 16;
     if (const char* de = experiment_env("NBODY_K9_SPLIT")) den = uint32_t(atoi(de)) ? uint32_t(atoi(de)) : 16u;  // experiments only
     uint32_t s0, l0;

@@ -159,8 +159,8 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
 // Splitter sort (2048 < n <= kSplitterMaxN).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kSplitMaxBuckets = 2048;               // B <= 2048: splitters fit LDS (24 KB)
-constexpr uint32_t kSampleMax       = 4096;               // pairs the sample block sorts in LDS (48 KB)
-constexpr uint32_t kBucketCap       = 4096;               // pairs one block sorts in LDS (48 KB); larger buckets: slow global path
+constexpr uint32_t kSampleMax       = 4096;               // pairs the sample block sorts (48 KB of LDS for its merge rounds)
+constexpr uint32_t kBucketCap       = 4096;               // pairs one block sorts (48 KB of LDS for its merge rounds); larger buckets: slow global path
 constexpr uint32_t kSplitterMaxN    = 768u * kSplitMaxBuckets;  // average bucket <= 768: the largest stays far below the cap
 constexpr int kSampleThreads = 1024, kBucketThreads = 512;
 

@@ -313,8 +313,22 @@ def test_sort_with_a_sample_that_misses_the_data(nb, oracle):
     """The splitters come from a regular sample of the input.  Here every sampled position holds a body from one corner of the
     box and every other position a body from the opposite corner: all splitters fall among the first, one bucket receives
     everything else — more than a block ranks in LDS — and takes one of the slow paths.  Same permutation."""
-    for n in (30000, 3500):  # one bucket of ~29 700 pairs (in place in global memory); one of ~3 470 (the sorting network in LDS)
+    # one bucket of ~29 700 pairs (in place in global memory); one of ~3 470 and one of ~2 040 (the block sort with 8 and with 4 pairs
+    # per thread)
+    for n in (30000, 3500, 2060):
         _sample_misses_the_data(nb, oracle, n)
+
+
+def test_sort_at_the_sizes_where_its_block_shapes_change(nb, oracle):
+    """250 000 pairs: 512 buckets, a 2048-pair sample (two pairs per thread of the sample block), counting / scatter blocks of 256
+    threads; 300 000: the same sample, counting / scatter blocks of 1024 threads (above 2^18 pairs)."""
+    rng = np.random.default_rng(17)
+    for n in (250000, 300000):
+        hs = nb.HostSystem(1, 3, n)
+        hs.x[:], hs.m[:] = rng.uniform(-3, 5, (n, 3)), 1.0
+        ref = oracle.State(1, 3, n)
+        ref.x[:], ref.m[:] = hs.x, hs.m
+        _sorted_perm_check(nb, oracle, hs, ref)
 
 
 def _sample_misses_the_data(nb, oracle, n):

@@ -1584,7 +1584,7 @@ __global__ __launch_bounds__((kSmallMpThreads<T, D>)) void ot_multipole_small_ke
     ot_multipole_chunk_body<T, D, NT>(0, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
     return;
   }
-  if (threadIdx.x >= uint32_t(kMpChunk)) return;  // (the chunks of kMpChunk ranks and the crown are written for kMpChunk threads)
+  if (threadIdx.x >= uint32_t(kMpChunk)) return;  // (the chunks of kMpChunk ranks and the crown are written for kMpChunk threads; waves that have ended take no part in a block barrier)
   const uint32_t chunks = (total + kMpChunk - 1) / kMpChunk;
   for (uint32_t b = 0; b < chunks && b < max_chunks; ++b) {
     ot_multipole_chunk_body<T, D, kMpChunk>(b, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
@@ -2595,7 +2595,10 @@ static int ot_tree_run(nbody_octree* t, hipStream_t st) {
     }
     return NBODY_OK;
   }
-  if ((t->build == 0 || t->build == 3) && max_chunks <= kSmallChunks) {
+  // one block for the whole tree where that is one chunk's work: a single chunk of kMpChunk ranks, or — in float — of 1024 (more cells
+  // than that, rare: chunk after chunk, then the crown).  Double trees of two or three chunks take the two launches below: their
+  // chunks side by side on two CUs + the crown are 22 us, one after the other in one block 30 (n = 1000)
+  if ((t->build == 0 || t->build == 3) && (max_chunks == 1 || (sizeof(T) == 4 && max_chunks <= kSmallChunks))) {
     hipLaunchKernelGGL((ot_multipole_small_kernel<T, D>), dim3(1), dim3((kSmallMpThreads<T, D>)), 0, st, tree, t->cells, t->lvl_count, t->later,
                        t->later_mask, t->capacity, t->max_cells, max_chunks);
     NB_HIP(hipGetLastError());

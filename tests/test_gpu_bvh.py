@@ -319,6 +319,25 @@ def test_sort_with_a_sample_that_misses_the_data(nb, oracle):
         _sample_misses_the_data(nb, oracle, n)
 
 
+def test_sort_random_sizes_and_clustered_keys(nb, oracle):
+    """Two dozen sizes drawn at random over the one-block and the splitter sort's range, half of them with the bodies in a few tight
+    clusters (keys that share most of their bits: buckets of very different sizes, every pairs-per-thread form of the block sort)."""
+    rng = np.random.default_rng(23)
+    for case in range(24):
+        n = int(rng.integers(2, 5000)) if case % 3 == 0 else int(rng.integers(5000, 180000))
+        dim = 3 if case % 2 == 0 else 2
+        x = rng.uniform(-3, 5, (n, dim))
+        if case % 4 >= 2:
+            centres = rng.uniform(-3, 5, (max(1, n // 3000), dim))
+            x = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 1e-3, (n, dim)) * rng.uniform(0.01, 1.0, (n, 1))
+            x[0] = 40.0  # an escaper: the box is much larger than the clusters
+        hs = nb.HostSystem(1, dim, n)
+        hs.x[:], hs.m[:] = x, 1.0
+        ref = oracle.State(1, dim, n)
+        ref.x[:], ref.m[:] = hs.x, hs.m
+        _sorted_perm_check(nb, oracle, hs, ref)
+
+
 def test_sort_at_the_sizes_where_its_block_shapes_change(nb, oracle):
     """250 000 pairs: 512 buckets, a 2048-pair sample (two pairs per thread of the sample block), counting / scatter blocks of 256
     threads; 300 000: the same sample, counting / scatter blocks of 1024 threads (above 2^18 pairs)."""

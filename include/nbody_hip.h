@@ -74,8 +74,9 @@ typedef struct nbody_state {
  *      nbody_bvh_set_launch_order;
  *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)).
  * 2.2: nbody_bvh_read what = 6 and nbody_bvh_opening_thresholds (the opening test as one compare), nbody_all_pairs_pair_rule;
- *      the measured forms that are not shipped (traversal 3 / 4 / 6, octree build 2 / 4) are refused by this library. */
-#define NBODY_HIP_ABI_VERSION 2002
+ *      the measured forms that are not shipped (traversal 3 / 4 / 6, octree build 2 / 4) are refused by this library.
+ * 2.3: nbody_all_pairs_status; nbody_stream_sync / nbody_download return NBODY_ERR_STATE after a failed K1 chunk hand-off. */
+#define NBODY_HIP_ABI_VERSION 2003
 int nbody_abi_version(void);
 
 /* Last error message of the calling thread ("" if none). */
@@ -90,6 +91,23 @@ int nbody_device_info(int device, char* arch_out, size_t arch_len, int* cu_count
  *   a[i] = c * sum_{j != i} m[j] * (x[j] - x[i]) / (pow(|x[j]-x[i]|^2, 3/2) + eps(T))
  * for owned bodies i; sources j = 0..sz-1 staged through LDS tiles. */
 int nbody_all_pairs_force(const nbody_state* s, void* stream);
+
+/* K1's in-kernel chunk hand-off, and how it fails.  From 2048 bodies on, the source range is cut into >= 16 chunks over grid.y;
+ * the block of chunk y adds its sum into `a` after the block of chunk y - 1 has (a turn word per group of targets), which fixes
+ * the rounding order without a scratch array or a second launch.  A block waits only for blocks of smaller linear index.  That
+ * this terminates rests on an ASSUMPTION about the dispatcher (true of every GPU this library targets, stated nowhere in the
+ * ISA): the workgroups of a grid are started in linear index order, so the oldest unfinished block never waits.  The reference's
+ * loop (src/all_pairs.h:14-27) cannot return garbage silently, and neither does this: a wave that has waited for its turn past
+ * the poll budget (minutes) gives up, the group's rows of `a` end as NaN — never as a finite partial sum — and a sticky
+ * per-stream status word is set on the device.  nbody_stream_sync, nbody_download and nbody_all_pairs_status on that stream then
+ * return NBODY_ERR_STATE with a message naming the target block, the group and the chunk, until the status is cleared.
+ *
+ * nbody_all_pairs_status waits for `stream` and writes (out may be NULL)
+ *   out[0] = 1 if a hand-off has failed, out[1..3] = target block, target group, chunk of the first failure,
+ *   out[4] = polls made by waves that had to wait for their turn, out[5] = number of waves that had to wait
+ * accumulated over every K1 launch of this stream since the last clear; clear != 0 zeroes them after the read.  A stream that
+ * has never run the chunked K1 reports zeros.  In normal operation nobody waits: out[4] = out[5] = 0. */
+int nbody_all_pairs_status(void* stream, uint64_t out[6], int clear);
 
 /* K2. Replaces all_pairs_collapsed_force (src/all_pairs.h:29-50) with its INTENDED semantics
  * (64-bit pair space, all D components; the reference wraps the pair count at 2^32 and drops

@@ -55,7 +55,7 @@ ABI_SYMBOLS = [
     "nbody_ctx_configure_all_pairs", "nbody_ctx_set_shard", "nbody_all_pairs_describe",
     "nbody_comm_get_unique_id", "nbody_comm_create", "nbody_comm_create_all", "nbody_comm_destroy", "nbody_comm_world",
     "nbody_comm_rank", "nbody_comm_rccl_version", "nbody_shard_range", "nbody_comm_group_begin", "nbody_comm_group_end",
-    "nbody_allgather_positions", "nbody_bvh_opening_thresholds", "nbody_all_pairs_pair_rule",
+    "nbody_allgather_positions", "nbody_bvh_opening_thresholds", "nbody_all_pairs_pair_rule", "nbody_all_pairs_status",
 ]
 ABI_MAJOR = 2
 COMM_ID_BYTES = 128
@@ -157,6 +157,18 @@ def all_pairs_pair_rule(st, stream=None):
     sparse, vol = C.c_int(), C.c_double()
     _check(lib().nbody_all_pairs_pair_rule(C.byref(st), C.c_void_p(stream), C.byref(sparse), C.byref(vol)))
     return bool(sparse.value), vol.value
+
+
+def all_pairs_status(stream=None, clear=False, check=True):
+    """K1's chunk hand-off status of a stream (nbody_all_pairs_status; waits for the stream): a dict with `failed`, the
+    (block, group, chunk) of the first failure, and `polls` / `waits` — how often waves had to wait for their turn.  Raises
+    NbodyError while a failure is recorded, unless check is False."""
+    out = (C.c_uint64 * 6)()
+    rc = lib().nbody_all_pairs_status(C.c_void_p(stream), out, 1 if clear else 0)
+    if check:
+        _check(rc)
+    return {"failed": bool(out[0]), "block": int(out[1]), "group": int(out[2]), "chunk": int(out[3]), "polls": int(out[4]),
+            "waits": int(out[5]), "rc": rc}
 
 
 def shard_range(n, rank, world):

@@ -245,19 +245,42 @@ constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the
 // sums added in slice order through LDS — and adds that sum s_y to the target's running total IN CHUNK ORDER:
 //     a = c * (((s_0 + s_1) + s_2) + ...),
 // the total living in `a` itself.  Block (b, y) waits until turn[b] == y (block (b, y - 1) has added its sum), adds, and passes the
-// turn on; the last chunk applies c.  No chunk-sum scratch (403 MB at N = 2^20 until round 3) and no combine launch.  Progress: a
-// block waits only for blocks of smaller linear index, which the dispatcher started earlier (workgroups are dealt to the XCDs
-// round-robin and started in order on each), so the unfinished block of smallest index is always running and never waits; in
-// practice nobody waits at all — block (b, y - 1) finished a whole round of blocks earlier.  A wait that outlasts kTurnSpins polls
-// (seconds) gives up and poisons its targets with NaN rather than hang the queue.  The running total is read and written with
-// agent-scope accesses (it changes hands between CUs and XCDs); what fixes the ROUNDING is unchanged from rounds 2-3, so every shard
-// window still sums exactly as the whole system does.
-constexpr uint32_t kTurnSpins = 1u << 26;
+// turn on; the last chunk applies c.  No chunk-sum scratch (403 MB at N = 2^20 until round 3) and no combine launch.
+//
+// Progress rests on ONE assumption that is a property of the dispatcher, not of the ISA: a block waits only for blocks of smaller
+// linear index, and the workgroups of a grid are started in linear index order (dealt to the XCDs round-robin, in order on each),
+// so the unfinished block of smallest index is always running and never waits.  In practice nobody waits at all — block (b, y - 1)
+// finished a whole round of blocks earlier (k1_status.waits counts the waves that did poll, .polls their polls).
+//
+// If the assumption ever fails, the failure is LOUD (k1_status, nbody_all_pairs_status, nbody_stream_sync, nbody_download):
+//   * a wave that has polled h.spins times (kTurnSpins: minutes) gives up: it swaps kTurnPoison into the turn word, records
+//     (block, group, chunk) in the stream's sticky status block, and leaves `a` alone — unless the swap returned its own number
+//     (the turn came between the last poll and the swap: the total is this wave's, and it writes NaN);
+//   * every wave that finds kTurnPoison while polling leaves without touching `a`;
+//   * a turn is passed on with a compare-and-swap y -> y + 1; a predecessor that comes late finds the poison instead, so at that
+//     moment it is the only wave that will ever touch the group's total again, and it writes NaN over it.
+//   So a poisoned group ends as NaN (never as a finite partial sum), and the host call that waits for the stream returns
+//   NBODY_ERR_STATE naming the block and the chunk.
+// The running total is read and written with agent-scope accesses (it changes hands between CUs and XCDs): the predecessor's
+// stores are acknowledged (s_waitcnt 0) before its turn store is issued, the successor issues its loads after it has seen the turn.
+// What fixes the ROUNDING is unchanged from rounds 2-3, so every shard window still sums exactly as the whole system does.
+constexpr uint32_t kTurnSpins  = 1u << 26;
+constexpr uint32_t kTurnPoison = 0xffffffffu;
+struct k1_status {  // one per (device, stream), device memory, zeroed when allocated; sticky until nbody_all_pairs_status(..., clear)
+  uint32_t err, block, group, chunk;
+  unsigned long long polls, waits;
+};
+struct k1_handoff {
+  uint32_t* turn;     // one word per (target block, target group): the chunk whose sum is added next, or kTurnPoison
+  k1_status* status;
+  uint32_t spins;     // polls before a waiting wave gives up (kTurnSpins; lowered only by the experiments build's tests)
+  uint32_t delay;     // s_sleep(127) rounds before a turn is passed on (0; the experiments build's tests make successors wait)
+};
 template <typename T, int D, int R, int JS>
 __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
                                                                                    const T* __restrict__ x, T* a, T c, uint32_t sz,
                                                                                    uint32_t first, uint32_t count,
-                                                                                   uint32_t tiles_per_chunk, uint32_t* turn,
+                                                                                   uint32_t tiles_per_chunk, k1_handoff h,
                                                                                    const unsigned long long* __restrict__ ext) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kSgprWaves<JS> / JS;
@@ -336,61 +359,92 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   }
   if (jpart != 0) return;
   const uint32_t y = blockIdx.y, last = gridDim.y - 1u;
+  uint32_t* const tw = h.turn + blockIdx.x * TG + tgroup;  // nullptr + ... when there is one chunk: never dereferenced (y == last == 0)
   bool poisoned = false;
-  if (y > 0) {  // my turn?  (one word per (target block, target group); wave-uniform address: every lane reads the same value)
-    uint32_t spins = 0;
-    while (__hip_atomic_load(turn + blockIdx.x * TG + tgroup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != y) {
-      __builtin_amdgcn_s_sleep(8);
-      if (++spins > kTurnSpins) {
+  if (y > 0) {  // my turn?  (wave-uniform address: every lane reads the same value)
+    uint32_t spins = 0, seen;
+    bool mine = true;
+    while ((seen = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != y) {
+      if (seen == kTurnPoison) {  // somebody gave up on this group: the total is not mine to touch
+        mine = false;
+        break;
+      }
+      if (++spins > h.spins) {  // give up (see above)
+        uint32_t old = 0;
+        if (lane == 0) {
+          old = __hip_atomic_exchange(tw, kTurnPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (atomicCAS(&h.status->err, 0u, 1u) == 0u) {
+            h.status->block = blockIdx.x;
+            h.status->group = uint32_t(tgroup);
+            h.status->chunk = y;
+          }
+        }
+        old      = __builtin_amdgcn_readfirstlane(old);
+        mine     = old == y;
         poisoned = true;
         break;
       }
+      __builtin_amdgcn_s_sleep(8);
     }
+    if (spins && lane == 0) {
+      atomicAdd(&h.status->polls, (unsigned long long)spins);
+      atomicAdd(&h.status->waits, 1ull);
+    }
+    if (!mine) return;
   }
   // The total's R * D * 64 scalars of this target group are contiguous in `a`: through LDS (the slices' partials are spent) every
   // lane takes scalars e = q * 64 + lane, so each access is one full-width coalesced instruction — per component the lanes would
   // touch every line three times (measured: 3.2 GB of traffic per launch at N = 2^20 instead of 1.3).
   const uint32_t gbase = blockIdx.x * TB + tgroup * (64 * R);  // first target of the group
-  if constexpr (JS > 1) {
-    T* stage = partial + size_t(tgroup) * R * D * 64;  // [(jpart - 1 = 0) * TG + tgroup] block of the partials: read above, free now
+  auto add_sum = [&](bool nan) {  // nan: overwrite the group's total with NaN instead
+    if constexpr (JS > 1) {
+      T* stage = partial + size_t(tgroup) * R * D * 64;  // [(jpart - 1 = 0) * TG + tgroup] block of the partials: read above, free now
+      if (!nan) {
 #pragma unroll
-    for (int r = 0; r < R; ++r)
+        for (int r = 0; r < R; ++r)
 #pragma unroll
-      for (int k = 0; k < D; ++k) stage[(r * 64 + lane) * D + k] = acc[r][k];
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < R * D; ++q) {
-      const uint32_t e = uint32_t(q) * 64u + uint32_t(lane);
-      if (gbase + e / D < count) {
-        T* slot = a + uint64_t(gbase) * D + e;
-        T t     = stage[e];
-        if (y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;  // ((s_0 + s_1) + ...) + s_y
-        if (y == last) t = c * t;
-        if (poisoned) t = __builtin_nan("");
-        __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int k = 0; k < D; ++k) stage[(r * 64 + lane) * D + k] = acc[r][k];
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
       }
-    }
-  } else {
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      if (ti[r] < count) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-          T* slot = a + uint64_t(ti[r]) * D + k;
-          T t     = acc[r][k];
-          if (y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
-          if (y == last) t = c * t;
-          if (poisoned) t = __builtin_nan("");
+      for (int q = 0; q < R * D; ++q) {
+        const uint32_t e = uint32_t(q) * 64u + uint32_t(lane);
+        if (gbase + e / D < count) {
+          T* slot = a + uint64_t(gbase) * D + e;
+          T t     = nan ? T(__builtin_nan("")) : stage[e];
+          if (!nan && y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;  // ((s_0 + s_1) + ...) + s_y
+          if (!nan && y == last) t = c * t;
           __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
       }
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        if (ti[r] < count) {
+#pragma unroll
+          for (int k = 0; k < D; ++k) {
+            T* slot = a + uint64_t(ti[r]) * D + k;
+            T t     = nan ? T(__builtin_nan("")) : acc[r][k];
+            if (!nan && y > 0) t = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + t;
+            if (!nan && y == last) t = c * t;
+            __hip_atomic_store(slot, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
     }
-  }
-  if (y < last) {  // pass the turn on once the stores above have been acknowledged
+  };
+  add_sum(poisoned);
+  if (y < last && !poisoned) {  // pass the turn on once the stores above have been acknowledged
+    for (uint32_t d = 0; d < h.delay; ++d) __builtin_amdgcn_s_sleep(127);  // 0 rounds, except in the hand-off tests of the experiments build
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores are at the agent's coherence point
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) __hip_atomic_store(turn + blockIdx.x * TG + tgroup, y + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t held = y;
+    if (lane == 0) {
+      __hip_atomic_compare_exchange_strong(tw, &held, y + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    held = __builtin_amdgcn_readfirstlane(held);  // what the word held: y, or kTurnPoison left by a successor that gave up
+    if (held != y) add_sum(true);
   }
 }
 
@@ -407,7 +461,7 @@ struct scratch_buf {
 struct packed_slot {
   int device;
   hipStream_t stream;
-  scratch_buf buf[4];  // 0: packed sources, 1: K1 per-chunk sums, 2: energies work area, 3: bounding-box keys
+  scratch_buf buf[5];  // 0: packed sources, 1: K1 turn words, 2: energies work area, 3: bounding-box keys, 4: K1 hand-off status (k1_status)
   std::vector<void*> retired;
 };
 std::mutex g_packed_mu;
@@ -437,6 +491,12 @@ int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out) {
   }
   void* fresh = nullptr;
   NB_HIP(hipMalloc(&fresh, bytes));  // on the stream's device: the caller holds a device_guard
+  if (which == 4) {                  // the status block starts clean and is never re-allocated (fixed size)
+    if (hipError_t e = hipMemset(fresh, 0, bytes); e != hipSuccess) {
+      (void)hipFree(fresh);
+      return hip_fail(e, "hipMemset(k1_status)", __FILE__, __LINE__);
+    }
+  }
   if (slot->buf[which].ptr) slot->retired.push_back(slot->buf[which].ptr);
   slot->buf[which].ptr = fresh;
   slot->buf[which].cap = bytes;
@@ -580,21 +640,26 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  uint32_t* turn = nullptr;
+  k1_handoff h{nullptr, nullptr, kTurnSpins, 0u};
   if (plan.chunks > 1) {  // before anything is queued: a failed reservation leaves the stream untouched
     void* q = nullptr;
     if (int r = ap_scratch_get(st, 1, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), &q)) return r;
-    turn = static_cast<uint32_t*>(q);
+    h.turn = static_cast<uint32_t*>(q);
+    if (int r = ap_scratch_get(st, 4, sizeof(k1_status), &q)) return r;
+    h.status = static_cast<k1_status*>(q);
+    // -DNBODY_EXPERIMENTS builds only (tests/test_gpu_all_pairs.py: the hand-off made to wait, and made to fail)
+    if (const char* e = experiment_env("NBODY_K1_TURN_SPINS")) h.spins = uint32_t(strtoul(e, nullptr, 10));
+    if (const char* e = experiment_env("NBODY_K1_HANDOFF_DELAY")) h.delay = uint32_t(strtoul(e, nullptr, 10));
   }
   const unsigned long long* ext = nullptr;
   if (int r = ap_extent<T, D>(s, st, &ext)) return r;
   void* scratch = nullptr;
   if (int r = ap_pack_sources(s, st, &scratch)) return r;
   auto* packed = static_cast<src_rec<T, D>*>(scratch);
-  if (turn) NB_HIP(hipMemsetAsync(turn, 0, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), st));  // chunk 0 needs no turn; 1 is next
+  if (h.turn) NB_HIP(hipMemsetAsync(h.turn, 0, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), st));  // chunk 0 holds the turn
   hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
                      packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                     plan.tiles_per_chunk, turn, ext);
+                     plan.tiles_per_chunk, h, ext);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -682,8 +747,41 @@ int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
     if (!p.scalar || p.chunks <= 1) return int(NBODY_OK);
     size_t words = 0;
     with_k1_instance(p, [&](auto r, auto js) { words = sgpr_turn_words<decltype(r)::value, decltype(js)::value>(s->count); });
-    return words ? ap_scratch_get(st, 1, sizeof(uint32_t) * words, &q) : int(NBODY_OK);
+    if (!words) return int(NBODY_OK);
+    if (int rc = ap_scratch_get(st, 1, sizeof(uint32_t) * words, &q)) return rc;
+    return ap_scratch_get(st, 4, sizeof(k1_status), &q);
   });
+}
+
+// The hand-off status of a stream's K1 launches (see all_pairs_force_sgpr_kernel).  Waits for the stream.  out (may be NULL):
+// {err, block, group, chunk, polls, waits}.  Returns NBODY_ERR_STATE (and the message) while the sticky error word is set.
+int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear) {
+  const int dev = stream_device(st);
+  k1_status* dptr = nullptr;
+  {
+    std::lock_guard<std::mutex> lock(g_packed_mu);
+    for (auto& sl : g_packed_slots)
+      if (sl.stream == st && sl.device == dev) dptr = static_cast<k1_status*>(sl.buf[4].ptr);
+  }
+  k1_status h{};
+  if (dptr) NB_HIP(hipMemcpyAsync(&h, dptr, sizeof h, hipMemcpyDeviceToHost, st));
+  NB_HIP(hipStreamSynchronize(st));
+  if (dptr && clear && (h.err || h.polls || h.waits)) {
+    NB_HIP(hipMemsetAsync(dptr, 0, sizeof h, st));
+    NB_HIP(hipStreamSynchronize(st));
+  }
+  if (out) {
+    out[0] = h.err, out[1] = h.block, out[2] = h.group, out[3] = h.chunk;
+    out[4] = h.polls, out[5] = h.waits;
+  }
+  if (h.err) {
+    set_error("all-pairs: the chunk hand-off of target block %u (group %u) failed at source chunk %u: the block of chunk %u never passed "
+              "the turn on within the poll budget (workgroups not started in index order?).  `a` of that launch is not valid (the "
+              "group's rows are NaN).  The flag is sticky for this stream until nbody_all_pairs_status(stream, out, 1)",
+              h.block, h.group, h.chunk, h.chunk - 1u);
+    return NBODY_ERR_STATE;
+  }
+  return NBODY_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1032,6 +1130,15 @@ extern "C" int nbody_all_pairs_force(const nbody_state* s, void* stream) {
     using TG = decltype(tg);
     return all_pairs_dispatch<typename TG::type, TG::dim>(s, as_stream(stream));
   });
+}
+
+extern "C" int nbody_all_pairs_status(void* stream, uint64_t out[6], int clear) {
+  device_guard guard(stream_device(as_stream(stream)));
+  unsigned long long v[6] = {0, 0, 0, 0, 0, 0};
+  const int rc = ap_status_read(as_stream(stream), v, clear != 0);
+  if (out)
+    for (int i = 0; i < 6; ++i) out[i] = v[i];
+  return rc;
 }
 
 extern "C" int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream) {

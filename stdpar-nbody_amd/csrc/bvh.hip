@@ -63,7 +63,11 @@ struct nbody_bvh {
   int traversal   = 0;  // 0 = auto (wave-cooperative when nlevels <= 26), 1 = per-lane, 2 = wave-cooperative
   int launch_order = 0; // sweep: 0 = work items (cut groups first), 1 = one block per group in index order
   double theta      = 0.5;   // the opening angle the next build writes thresholds for (the last one a traversal was asked for)
-  double th2_built  = -1.0;  // theta^2 (in T) of the thresholds the records hold; -1: none
+  double th2_built  = -1.0;  // theta^2 (in T) of the thresholds the records hold; -1: none.  What the HOST believes after its
+                             // own eager calls; a recorded step changes the records whenever it is replayed, so:
+  bool ever_recorded = false;            // a build or traversal of this tree has been recorded: eager traversals always rethreshold
+  unsigned long long rec_id = 0;         // the capture whose recorded build / traversal last wrote the thresholds ...
+  double rec_th2            = -1.0;      // ... and the theta^2 it wrote them for (valid inside that capture only)
   bool counters_on = false, have_bbox = false, sorted = false, built = false;
 };
 
@@ -1192,6 +1196,11 @@ static int build_run(nbody_bvh* t, const nbody_state* s, hipStream_t st) {
       l = -1;
     }
   }
+  if (const unsigned long long cap = capture_id(st)) {  // replayed at times the host does not see: th2_built says nothing any more
+    t->ever_recorded = true;
+    t->rec_id        = cap;
+    t->rec_th2       = double(th2);
+  }
   t->th2_built = double(th2);
   return NBODY_OK;
 }
@@ -1203,12 +1212,22 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
   const T th2 = th * th;  // src/bvh.h:252, in T
   auto* node = static_cast<const tree_rec<T>*>(t->node);
   t->theta   = theta;  // the next build writes the records' opening thresholds for this angle
-  if (t->th2_built != double(th2)) {
+  // The sweep trusts the thresholds in the records.  The host knows what they hold only along its own eager calls: a recorded
+  // step rewrites them whenever it is replayed.  So a recorded traversal skips the rewrite only behind a build (or traversal) of
+  // the SAME capture for the same angle, and once anything of this tree has been recorded an eager traversal always rewrites.
+  const unsigned long long cap = capture_id(st);
+  const bool fresh = cap ? (t->rec_id == cap && t->rec_th2 == double(th2)) : (!t->ever_recorded && t->th2_built == double(th2));
+  if (!fresh) {
     hipLaunchKernelGGL((rethreshold_kernel<T, D>), dim3((t->nnodes + kB - 1) / kB), dim3(kB), 0, st,
                        static_cast<tree_rec<T>*>(t->node), t->nnodes, th2);
     NB_HIP(hipGetLastError());
-    t->th2_built = double(th2);
   }
+  if (cap) {
+    t->ever_recorded = true;
+    t->rec_id        = cap;
+    t->rec_th2       = double(th2);
+  }
+  t->th2_built = double(th2);
   // auto: the wave-cooperative sweep needs enough waves in flight to hide its serial chain.  Measured in the CLI's step loop on
   // 256 CUs (ms per whole bvh step over the first 200 steps of the galaxy, sweep / per-lane): f64 (hand-scheduled sweep) 0.90 / 0.85
   // at 4*10^4, 1.0 / 1.0 at 6*10^4, 1.1 / 1.15 at 8*10^4, 1.2 / 1.25 at 10^5, 1.3 / 1.5 at 1.3*10^5, 2.05 / 3.45 at 2.5*10^5, 3.45 / 7.1

@@ -53,6 +53,15 @@ inline int current_device() {
   return hipGetDevice(&d) == hipSuccess ? d : -1;
 }
 
+// 0 unless `st` is recording (nbody_graph_begin): then the capture's id
+inline unsigned long long capture_id(hipStream_t st) {
+  if (st == nullptr) return 0;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  unsigned long long id     = 0;
+  if (hipStreamGetCaptureInfo(st, &cs, &id) != hipSuccess || cs != hipStreamCaptureStatusActive) return 0;
+  return id ? id : ~0ull;
+}
+
 // device a stream was created on; the NULL stream belongs to whatever device is current
 inline int stream_device(hipStream_t st) {
   if (st == nullptr) return current_device();
@@ -509,7 +518,8 @@ inline int check_tuning(int split, int tpt, int path) {
 // all_pairs.hip: per-(device, stream) packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
 int ap_scratch_reserve(hipStream_t st, const nbody_state* view);
 void ap_scratch_release(hipStream_t st);
-int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 chunk sums, 2 energies, 3 bounding-box keys
+int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 turn words, 2 energies, 3 bounding-box keys, 4 K1 hand-off status
+int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear);  // waits for the stream; NBODY_ERR_STATE while a K1 hand-off failure is recorded
 int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk);
 

@@ -138,8 +138,7 @@ extern "C" int nbody_download(nbody_ctx* c, void* m, void* x, void* v, void* a, 
   if (v) NB_HIP(rows(v, c->v));
   if (a) NB_HIP(rows(a, c->a));
   if (ao) NB_HIP(rows(ao, c->ao));
-  NB_HIP(hipStreamSynchronize(c->stream));
-  return NBODY_OK;
+  return ap_status_read(c->stream, nullptr, false);  // waits for the stream; a failed K1 chunk hand-off must not pass for a result
 }
 
 extern "C" int nbody_ctx_state(nbody_ctx* c, nbody_state* out) {
@@ -186,8 +185,7 @@ extern "C" void* nbody_ctx_stream(nbody_ctx* c) { return c ? static_cast<void*>(
 
 extern "C" int nbody_stream_sync(void* stream) {
   device_guard guard(stream_device(as_stream(stream)));
-  NB_HIP(hipStreamSynchronize(as_stream(stream)));
-  return NBODY_OK;
+  return ap_status_read(as_stream(stream), nullptr, false);  // hipStreamSynchronize + the stream's K1 hand-off status (sticky)
 }
 
 // ---- step graphs ---------------------------------------------------------------------------------------------

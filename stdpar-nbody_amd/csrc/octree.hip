@@ -1303,21 +1303,22 @@ __global__ __launch_bounds__(kMpChunk) void ot_multipole_chunks_kernel(ot_tree<T
 constexpr uint32_t kMpMaxBlocks = 8192;  // blocks of the previous round a round can compact (32 KB of LDS): trees of up to 4.2 * 10^6 cells
 constexpr uint32_t kMpLater2    = 0x40000000u;
 
+// (written for kMpCrown threads; a larger block passes active = threadIdx.x < kMpCrown: its other threads only keep the barriers)
 __device__ __forceinline__ uint32_t ot_compact_masks(const uint32_t* __restrict__ mask, uint32_t nblocks, uint32_t* base,
-                                                      uint32_t* wsum, uint32_t* carry_s) {
+                                                      uint32_t* wsum, uint32_t* carry_s, bool active = true) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) *carry_s = 0;
   ot_lds_barrier();
   for (uint32_t b0 = 0; b0 < nblocks; b0 += kMpCrown) {
     const uint32_t b = b0 + threadIdx.x;
-    const uint32_t v = b < nblocks ? uint32_t(__builtin_popcount(mask[b])) : 0u;
+    const uint32_t v = active && b < nblocks ? uint32_t(__builtin_popcount(mask[b])) : 0u;
     uint32_t inc     = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const uint32_t up = __shfl_up(inc, off, 64);
       if (lane >= uint32_t(off)) inc += up;
     }
-    if (lane == 63) wsum[wave] = inc;
+    if (lane == 63 && active) wsum[wave] = inc;
     ot_lds_barrier();
     uint32_t before = *carry_s, total = 0;
 #pragma unroll
@@ -1326,7 +1327,7 @@ __device__ __forceinline__ uint32_t ot_compact_masks(const uint32_t* __restrict_
       if (uint32_t(w) < wave) before += q;
       total += q;
     }
-    if (b < nblocks) base[b] = before + inc - v;
+    if (active && b < nblocks) base[b] = before + inc - v;
     ot_lds_barrier();
     if (threadIdx.x == 0) *carry_s += total;
     ot_lds_barrier();
@@ -1474,7 +1475,7 @@ __global__ __launch_bounds__(kMpCrown) void ot_multipole_round_kernel(ot_tree<T,
 template <typename T, int D>
 __device__ __forceinline__ void ot_multipole_crown_body(T (*sm)[4], ot_tree<T, D> tree, const ot_cell* cells, const uint32_t* lvl_count,
                                                         const uint32_t* later, const uint32_t* later_mask, uint32_t max_cells,
-                                                        int after_round) {
+                                                        int after_round, bool active = true) {
   constexpr uint32_t NCH = 1u << D;
   constexpr int ML       = kMaxLevels<D>;
   __shared__ uint32_t base[kMpMaxBlocks + 1];
@@ -1486,7 +1487,7 @@ __device__ __forceinline__ void ot_multipole_crown_body(T (*sm)[4], ot_tree<T, D
   const uint32_t nblocks  = after_round ? lvl_count[ML + 6] : (total + kMpChunk - 1) / kMpChunk;
   const uint32_t pending  = after_round ? kMpLater2 : kMpLater;
   if (nblocks <= 1 || nblocks > kMpMaxBlocks) return;  // (a single block leaves nothing)
-  const uint32_t count = ot_compact_masks(later_mask, nblocks, base, wsum, &carry_s);
+  const uint32_t count = ot_compact_masks(later_mask, nblocks, base, wsum, &carry_s, active);
   if (threadIdx.x == 0) lvl_hi = -1;
   ot_lds_barrier();
   if (count <= uint32_t(kMpCrown)) {
@@ -1494,7 +1495,7 @@ __device__ __forceinline__ void ot_multipole_crown_body(T (*sm)[4], ot_tree<T, D
     uint32_t node = 0, r = 0;
     T cm[NCH], cp[NCH][D];
     uint32_t slot[NCH];
-    if (threadIdx.x < count) {
+    if (active && threadIdx.x < count) {
       r                = ot_compact_item<ML>(threadIdx.x, base, nblocks, later_mask, later);
       const ot_cell cl = cells[r];
       node             = cl.node;
@@ -1541,13 +1542,13 @@ __device__ __forceinline__ void ot_multipole_crown_body(T (*sm)[4], ot_tree<T, D
     return;
   }
   // more waiting cells than threads: each level's straight from the slots
-  for (uint32_t b = threadIdx.x; b < nblocks; b += kMpCrown) {
+  for (uint32_t b = active ? threadIdx.x : nblocks; b < nblocks; b += kMpCrown) {
     const uint32_t m = later_mask[b];
     if (m) atomicMax(&lvl_hi, 31 - __builtin_clz(m));
   }
   __syncthreads();
   for (int l = lvl_hi; l >= 0; --l) {
-    for (uint32_t b = threadIdx.x; b < nblocks; b += kMpCrown)
+    for (uint32_t b = active ? threadIdx.x : nblocks; b < nblocks; b += kMpCrown)
       if ((later_mask[b] >> l) & 1u) ot_multipole_cell<T, D>(tree, cells[later[b * uint32_t(ML) + uint32_t(l)]].node);
     __threadfence_block();
     __syncthreads();  // (waits for the stores: the next level reads them back)
@@ -1584,7 +1585,9 @@ __global__ __launch_bounds__((kSmallMpThreads<T, D>)) void ot_multipole_small_ke
     ot_multipole_chunk_body<T, D, NT>(0, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
     return;
   }
-  if (threadIdx.x >= uint32_t(kMpChunk)) return;  // (the chunks of kMpChunk ranks and the crown are written for kMpChunk threads; waves that have ended take no part in a block barrier)
+  // The chunks of kMpChunk ranks and the crown are written for kMpChunk threads.  In float this block has 1024: the upper half
+  // stays through every barrier and does nothing in between (a chunk gives ranks past its end no cell; the crown is told).
+  const bool active     = threadIdx.x < uint32_t(kMpChunk);
   const uint32_t chunks = (total + kMpChunk - 1) / kMpChunk;
   for (uint32_t b = 0; b < chunks && b < max_chunks; ++b) {
     ot_multipole_chunk_body<T, D, kMpChunk>(b, sm, tree, cells, lvl_count, later, later_mask, capacity, max_cells);
@@ -1593,7 +1596,7 @@ __global__ __launch_bounds__((kSmallMpThreads<T, D>)) void ot_multipole_small_ke
       __syncthreads();
     }
   }
-  if (chunks > 1) ot_multipole_crown_body<T, D>(sm, tree, cells, lvl_count, later, later_mask, max_cells, 0);
+  if (chunks > 1) ot_multipole_crown_body<T, D>(sm, tree, cells, lvl_count, later, later_mask, max_cells, 0, active);
 }
 
 // ---- traversal (src/octree.h:226-263) -----------------------------------------------------------------------------------

@@ -64,9 +64,8 @@ static __global__ __launch_bounds__(kSortB) void radix_scan_rows_kernel(uint32_t
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
-// FUSED: the per-digit row scan over the blocks is done here, by every block for itself (thread d adds row d of the histogram up
-// to its own block and to the end) — one launch less per pass.  For few blocks only (the rows are read once per block).
-template <bool FUSED>
+// (Until round 4 a FUSED form did the per-digit row scan here, by every block for itself — one launch less per pass for sorts of
+// up to 16 blocks.  Those sizes now take the one-block or the splitter sort; the form was unreachable and is gone.)
 static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ idx_in,
                                                            uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out,
                                                            uint32_t n, int shift, const uint32_t* __restrict__ hist,
@@ -102,23 +101,8 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
     if (valid && before == 0) wcnt[wave][d] = base + uint32_t(__popcll(same));
     __builtin_amdgcn_wave_barrier();
   }
-  __shared__ uint32_t dtot[256];   // FUSED: the digit totals this block computed itself
-  uint32_t before_me = 0;          // FUSED: keys with this digit in the blocks before this one
   {  // digit = threadIdx.x: exclusive scan of totals[0..255]; within a wave here, wave offsets after the barrier
-    uint32_t v;
-    if constexpr (FUSED) {
-      const uint32_t* row = hist + uint64_t(threadIdx.x) * nblk;
-      uint32_t tot = 0;
-      for (uint32_t b = 0; b < nblk; ++b) {
-        const uint32_t h = row[b];
-        before_me += b < blockIdx.x ? h : 0u;
-        tot += h;
-      }
-      dtot[threadIdx.x] = tot;
-      v                 = tot;
-    } else {
-      v = totals[threadIdx.x];
-    }
+    const uint32_t v = totals[threadIdx.x];
     uint32_t inc     = v;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -132,8 +116,8 @@ static __global__ __launch_bounds__(kSortB) void radix_scatter_kernel(const uint
   {
     uint32_t woff = 0;
     for (int w = 0; w < wave; ++w)  // totals of the earlier 64-digit groups
-      woff += dbase[w * 64 + 63] + (FUSED ? dtot[w * 64 + 63] : totals[w * 64 + 63]);
-    uint32_t run = woff + dbase[threadIdx.x] + (FUSED ? before_me : hist[uint64_t(threadIdx.x) * nblk + blockIdx.x]);
+      woff += dbase[w * 64 + 63] + totals[w * 64 + 63];
+    uint32_t run = woff + dbase[threadIdx.x] + hist[uint64_t(threadIdx.x) * nblk + blockIdx.x];
 #pragma unroll
     for (int w = 0; w < kSortB / 64; ++w) {
       uint32_t cw          = wcnt[w][threadIdx.x];
@@ -593,9 +577,10 @@ inline size_t radix_sort_scratch_words(uint32_t n) {
   return rows * (nblk + 1) + (rows + 1) + 3 * rows + (size_t(n) + 1) / 2 + 8;
 }
 
-// hist needs radix_sort_scratch_words(n) u32 (8-byte aligned).  Sorts by (key bits [0, key_bits), position): the pairs start in
-// (keys[0], identity) and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.  Both buffers of
-// keys / idx are overwritten.
+// hist needs radix_sort_scratch_words(n) u32 (8-byte aligned).  Sorts by (key, position): the pairs start in (keys[0], identity)
+// and end in (keys[final], idx[final]); returns `final` (0 or 1) through *final_buf.  Both buffers of keys / idx are overwritten.
+// key_bits: bits [key_bits, 64) of every key MUST be zero (63 for the 3D curves, 64 in 2D) — the one-block and the splitter sort
+// compare all 64 bits, the radix passes stop at key_bits, and under that condition they agree.  n == 0: nothing is launched.
 inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSortTile; }
 // Tried and not kept (round 3): taking the NEXT pass's histogram inside the scatter — it knows the block every key lands in —
 // with one global atomicAdd per key into three rotating histogram buffers (7 launches fewer per sort).  Bit-exact, but the
@@ -604,13 +589,14 @@ inline uint32_t radix_sort_blocks(uint32_t n) { return (n + kSortTile - 1) / kSo
 // Also tried and not kept: 11-bit digits (6 passes instead of 8; 2048 bins, 40 KB of LDS in the scatter, 11 ballots per strip).
 // Octree step, graph replay, before -> after: N = 10^4 0.214 -> 0.226 ms, 10^5 0.445 -> 0.437, 10^6 2.81 -> 2.92 — the two
 // passes saved are paid back by the wider bins everywhere but at 10^5.
-// Measured (profiles/r03/small_trees_kernel_stats.txt): at 49 blocks (N = 10^5) the fused scatter takes 13.2 us against 8 + 5 for
-// scatter + scan — nothing gained; at 5 blocks (N = 10^4) the octree step goes from 0.324 to 0.278 ms.
-constexpr uint32_t kSortFusedBlocks = 16;  // up to 32 768 keys: every block scans the 256 x nblk histogram itself
 
 inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int key_bits, uint32_t* hist, hipStream_t st,
                             int* final_buf) {
   const uint32_t nblk    = radix_sort_blocks(n);
+  if (n == 0) {
+    *final_buf = 0;
+    return NBODY_OK;
+  }
   if (nblk == 1) {
     hipLaunchKernelGGL(sort_one_block_kernel, dim3(1), dim3(kOneBlockThreads), 0, st, keys[0], keys[1], idx[1], n);
     NB_HIP(hipGetLastError());
@@ -650,17 +636,11 @@ inline int radix_sort_pairs(uint64_t* keys[2], uint32_t* idx[2], uint32_t n, int
   for (int shift = 0; shift < key_bits; shift += 8) {
     hipLaunchKernelGGL(radix_hist_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], n, shift, hist, nblk);
     NB_HIP(hipGetLastError());
-    if (nblk <= kSortFusedBlocks) {  // small sorts are bound by their dependent launches: 2 per pass instead of 3
-      hipLaunchKernelGGL(radix_scatter_kernel<true>, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1], idx[cur ^ 1],
-                         n, shift, hist, hist + 256u * size_t(nblk), nblk);
-      NB_HIP(hipGetLastError());
-    } else {
-      hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kSortB), 0, st, hist, nblk, hist + 256u * size_t(nblk));
-      NB_HIP(hipGetLastError());
-      hipLaunchKernelGGL(radix_scatter_kernel<false>, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1],
-                         idx[cur ^ 1], n, shift, hist, hist + 256u * size_t(nblk), nblk);
-      NB_HIP(hipGetLastError());
-    }
+    hipLaunchKernelGGL(radix_scan_rows_kernel, dim3(256), dim3(kSortB), 0, st, hist, nblk, hist + 256u * size_t(nblk));
+    NB_HIP(hipGetLastError());
+    hipLaunchKernelGGL(radix_scatter_kernel, dim3(nblk), dim3(kSortB), 0, st, keys[cur], idx_in, keys[cur ^ 1], idx[cur ^ 1], n, shift,
+                       hist, hist + 256u * size_t(nblk), nblk);
+    NB_HIP(hipGetLastError());
     cur ^= 1;
     idx_in = idx[cur];
   }

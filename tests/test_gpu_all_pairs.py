@@ -677,3 +677,112 @@ def test_config2_as_written_100_steps(nb, oracle):
     p1 = (out.m[:, None] * out.v).sum(axis=0)
     assert np.abs(p1 - p0).max() <= 1e-11 * np.abs(out.m[:, None] * out.v).sum()
     dev.close()
+
+
+def test_k1_handoff_status_of_ordinary_runs(nb):
+    """K1's chunks add their sums into `a` in turn (all_pairs.hip, all_pairs_force_sgpr_kernel).  The stream's status block must say
+    after ordinary launches — whole systems and rank windows, both precisions — that no hand-off failed; how many waves had to
+    poll for their turn is reported, not asserted (normally none: the predecessor finished a round of blocks earlier)."""
+    for dtype, n, first, count in ((1, 8192, 0, None), (0, 8192, 0, None), (1, 70001, 0, None), (1, 1 << 18, 1 << 17, 1 << 15)):
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+        assert "summed in turn" in nb.describe_all_pairs(dev.state(first, count))
+        for _ in range(3):
+            dev.all_pairs_force(first, count)
+        dev.sync()                                   # would raise NBODY_ERR_STATE
+        st = nb.all_pairs_status(dev.stream)
+        assert not st["failed"] and st["rc"] == 0, st
+        a = dev.download().a
+        lo, hi = first, first + (count if count is not None else n)
+        assert np.isfinite(a[lo:hi]).all()
+        dev.close()
+    # a stream that never ran the chunked kernel reports zeros
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", 600))
+    dev.all_pairs_force()
+    assert nb.all_pairs_status(dev.stream, clear=True) == {"failed": False, "block": 0, "group": 0, "chunk": 0, "polls": 0, "waits": 0, "rc": 0}
+    dev.close()
+
+
+@pytest.mark.parametrize("dtype", [1, 0])
+def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
+    """The hand-off under stress, through libnbody_hip_exp.so (the same kernel; only that build reads the two switches) in a child
+    process.  (1) NBODY_K1_HANDOFF_DELAY: every block sleeps before it passes the turn on, so its successors really wait: polls > 0
+    and `a` bitwise equal to the undelayed run — for the whole system, for a rank window and with two targets per lane.
+    (2) A turn that does not come within the budget (delay of milliseconds, NBODY_K1_TURN_SPINS = 3): nbody_stream_sync and
+    nbody_download return NBODY_ERR_STATE naming block and chunk, the status block holds the failure, and EVERY row of `a` is either
+    NaN or bitwise the right value — never a finite partial sum.  (3) The flag is sticky until cleared; after the clear the same
+    context computes the right forces again."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "stdpar-nbody_amd", "libnbody_hip_exp.so")
+    if not os.path.exists(lib):
+        pytest.skip("libnbody_hip_exp.so not built (make -C stdpar-nbody_amd experiments)")
+    code = textwrap.dedent(f"""
+        import os, sys, numpy as np
+        sys.path.insert(0, {os.path.join(root, 'tests')!r})
+        from conftest import load_package
+        nb = load_package()
+        nb.LIB_PATH = {lib!r}
+        dtype = {dtype}
+        def force(n, first=0, count=None, tpt=0, delay=None, spins=None, expect_failure=False):
+            for k, v in (("NBODY_K1_HANDOFF_DELAY", delay), ("NBODY_K1_TURN_SPINS", spins)):
+                os.environ.pop(k, None)
+                if v is not None:
+                    os.environ[k] = str(v)
+            dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+            if tpt:
+                dev.configure_all_pairs(0, tpt, 0)
+            dev.all_pairs_force(first, count)
+            if not expect_failure:
+                dev.sync()
+                st = nb.all_pairs_status(dev.stream)
+                a = dev.download().a.copy()
+                dev.close()
+                return a, st
+            return dev
+        for n, first, count, tpt in ((8192, 0, None, 0), (8192, 0, None, 2), (50000, 20000, 9000, 0), (3000, 0, None, 0)):
+            a0, st0 = force(n, first, count, tpt)
+            a1, st1 = force(n, first, count, tpt, delay=50)
+            assert not st0["failed"] and not st1["failed"], (st0, st1)
+            assert st1["polls"] > 0 and st1["waits"] > 0, ("nobody waited", n, st1)
+            assert np.array_equal(a0, a1), ("delayed hand-off changed a", n, first, count, tpt)
+            print("waited", n, first, count, tpt, st1["waits"], st1["polls"])
+        # the turn that never comes in time
+        n = 8192
+        a0, _ = force(n)
+        dev = force(n, delay=3000, spins=3, expect_failure=True)
+        try:
+            dev.sync()
+            raise SystemExit("nbody_stream_sync returned success after a failed hand-off")
+        except nb.NbodyError as e:
+            assert "error 3" in str(e) and "hand-off" in str(e) and "chunk" in str(e), str(e)
+        st = nb.all_pairs_status(dev.stream, check=False)
+        assert st["failed"] and st["rc"] == 3 and 1 <= st["chunk"] <= 15 and st["block"] < n // 64, st
+        hs = nb.HostSystem(dtype, 3, n)
+        try:
+            dev.download(hs)
+            raise SystemExit("nbody_download returned success after a failed hand-off")
+        except nb.NbodyError as e:
+            assert "hand-off" in str(e)
+        bad = np.isnan(hs.a).any(axis=1)
+        assert bad.any(), "a failed hand-off left no NaN"
+        assert np.array_equal(hs.a[~bad], a0[~bad]), "a finite row differs from the undisturbed run"
+        assert np.isnan(hs.a[bad]).all(), "a row is partly NaN"
+        print("failed as it should:", int(bad.sum()), "of", n, "rows NaN;", st)
+        # sticky, then cleared; the context works again
+        os.environ.pop("NBODY_K1_HANDOFF_DELAY"); os.environ.pop("NBODY_K1_TURN_SPINS")
+        try:
+            dev.sync()
+            raise SystemExit("the failure flag is not sticky")
+        except nb.NbodyError:
+            pass
+        assert nb.all_pairs_status(dev.stream, clear=True, check=False)["failed"]
+        dev.sync()
+        dev.all_pairs_force()
+        dev.sync()
+        assert np.array_equal(dev.download().a, a0)
+        assert not nb.all_pairs_status(dev.stream)["failed"]
+        dev.close()
+        print("ok")
+    """)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-1500:], r.stderr[-1500:])

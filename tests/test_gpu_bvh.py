@@ -350,6 +350,53 @@ def test_sort_at_the_sizes_where_its_block_shapes_change(nb, oracle):
         _sorted_perm_check(nb, oracle, hs, ref)
 
 
+def _sort_case(nb, oracle, rng, n, variant, dim=3):
+    x = rng.uniform(-3, 5, (n, dim))
+    if variant == "clustered":   # a few hundred tight clusters and an escaper: keys that share most of their bits
+        centres = rng.uniform(-3, 5, (max(1, n // 3000), dim))
+        x = centres[rng.integers(0, len(centres), n)] + rng.normal(0, 1e-3, (n, dim)) * rng.uniform(0.01, 1.0, (n, 1))
+        x[0] = 40.0
+    elif variant == "ties":      # a third of the bodies coincide with another one, a third sit within 1e-9 of one
+        src, kind = rng.integers(0, n, n), rng.integers(0, 3, n)
+        x = np.where((kind == 0)[:, None], x[src], np.where((kind == 1)[:, None], x[src] + 1e-9 * rng.standard_normal((n, dim)), x))
+    hs = nb.HostSystem(1, dim, n)
+    hs.x[:], hs.m[:] = x, 1.0
+    ref = oracle.State(1, dim, n)
+    ref.x[:], ref.m[:] = hs.x, hs.m
+    keys = _sorted_perm_check(nb, oracle, hs, ref)
+    if variant == "ties":
+        assert len(np.unique(keys)) < n
+    return keys
+
+
+def test_sort_above_the_splitter_range(nb, oracle):
+    """std::sort (src/bvh.h:47-95) has no size limit.  Here the splitter sort ends at 768 * 2048 = 1 572 864 pairs and larger inputs
+    take eight counting passes of 8 bits (radix_sort.hpp: radix_hist_kernel / radix_scan_rows_kernel / radix_scatter_kernel) — the
+    path every sort took until round 3.  The last splitter size, the first radix size and 2^21, with random, clustered and tied
+    keys: keys bit-exact against the oracle, permutation == oracle.sort_keys == stable argsort, gather checked."""
+    rng = np.random.default_rng(31)
+    _sort_case(nb, oracle, rng, 768 * 2048, "random")
+    for n in (768 * 2048 + 1, 1 << 21):
+        for variant in ("random", "clustered", "ties"):
+            _sort_case(nb, oracle, rng, n, variant)
+    _sort_case(nb, oracle, rng, 768 * 2048 + 4097, "random", dim=2)   # a ragged last block; 64-bit keys of the 2D curve
+
+
+def test_sort_with_2048_buckets(nb, oracle):
+    """(786 432, 1 572 864] pairs: the splitter sort with its largest bucket count (2048) and a 4096-pair sample.  10^6 and 2^20
+    are covered by the full-size tests; here the first size of the range, one inside and a clustered one."""
+    rng = np.random.default_rng(37)
+    _sort_case(nb, oracle, rng, 786433, "random")
+    _sort_case(nb, oracle, rng, 1200000, "ties")
+    _sort_case(nb, oracle, rng, 1500000, "clustered")
+
+
+def test_bvh_whole_force_phase_at_2pow21(nb, oracle):
+    """Twice config 4's size, beyond the splitter sort: every phase bit-exact (box, keys, permutation, tree, per-body traversal
+    counters), force within tolerance."""
+    _phases(nb, oracle, 1, 3, "galaxy", 1 << 21, 0.7)
+
+
 def _sample_misses_the_data(nb, oracle, n):
     dim = 3
     buckets = 4
@@ -481,6 +528,56 @@ def test_key_ties_match_the_reference_as_multisets(nb, oracle, golden_bvh_ties):
         nb.run(dev, "bvh", 4, 0.0)
         assert_frames_equal_as_multisets(dev.download().x, case["bvh_last_frame"], 1e-11)
         dev.close()
+
+
+def test_recorded_steps_and_eager_traversals_at_other_angles(nb):
+    """The sweep reads the opening thresholds the BUILD wrote into the records (one compare per node, no theta in the kernel); a
+    traversal at another angle rewrites them first.  What the records hold is tracked on the host — which a recorded step, replayed
+    later, changes behind its back.  Every order of (recorded build + traversal at 0.3, replayed) and (eager traversal at 0.9) must
+    give the per-lane form's result for the angle asked for: counters bit-exact, forces bitwise (the per-lane form takes theta as
+    an argument and never reads the thresholds)."""
+    n = 30000
+    hs = nb.build_model(1, 3, "galaxy", n)
+
+    def per_lane(theta):
+        d = nb.DeviceSystem.from_host(hs)
+        d.bvh.set_traversal(1)
+        d.bvh.enable_counters(True)
+        d.bvh_force(theta)
+        d.sync()
+        out = (d.download().a.copy(), d.bvh.read(5, d.stream))
+        d.close()
+        return out
+    want = {th: per_lane(th) for th in (0.3, 0.9)}
+    dev = nb.DeviceSystem.from_host(hs)
+    dev.bvh.set_traversal(2)
+    dev.bvh.enable_counters(True)
+    dev.bvh_force(0.3)   # eager first: buffers exist, the bodies are in key order (the sort is then the identity, a stays in place)
+    dev.sync()
+    st = dev.state()
+
+    def got():
+        dev.sync()
+        return dev.download().a.copy(), dev.bvh.read(5, dev.stream)
+
+    def same(a, b):
+        return np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert same(got(), want[0.3])
+    g = nb.StepGraph(dev, lambda: dev.bvh_force(0.3))          # records build (thresholds for 0.3) + traversal
+    only_force = nb.StepGraph(dev, lambda: dev.bvh.compute_force(st, 0.3, dev.stream))   # a traversal alone, recorded
+    dev.bvh.compute_force(st, 0.9, dev.stream)                 # eager, other angle: rewrites the thresholds
+    assert same(got(), want[0.9]), "eager traversal after a recording"
+    g.launch()                                                 # the replayed build writes 0.3 again, unseen by the host
+    assert same(got(), want[0.3]), "replay"
+    dev.bvh.compute_force(st, 0.9, dev.stream)                 # the case ADVICE r4 names: must not trust the host's memory of 0.9
+    assert same(got(), want[0.9]), "eager traversal at the angle the host last saw, after a replay at another"
+    only_force.launch()                                        # the records hold 0.9 now; the recorded traversal wants 0.3
+    assert same(got(), want[0.3]), "recorded traversal alone, replayed behind an eager one at another angle"
+    dev.bvh.build_tree(st, dev.stream)                         # eager build (for the last angle asked: 0.3), replay, eager 0.9
+    g.launch()
+    dev.bvh.compute_force(st, 0.9, dev.stream)
+    assert same(got(), want[0.9])
+    g.close(), only_force.close(), dev.close()
 
 
 def test_unshipped_forms_are_refused(nb):

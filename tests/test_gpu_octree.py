@@ -595,6 +595,24 @@ def test_octree_full_size(nb, oracle):
     assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[1]
 
 
+@pytest.mark.parametrize("n,theta", [(768 * 2048 + 1, 0.5), (1 << 21, 0.8)])
+def test_octree_above_the_splitter_sort_range(nb, oracle, n, theta):
+    """The octree's path keys go through the same sort entry as the bvh's; above 1 572 864 bodies that is the eight-pass radix
+    sort (radix_sort.hpp).  Tree size, root monopole and every body's visit counters bit-exact against the oracle's serial
+    insertion (src/octree.h:114-180), force within tolerance."""
+    ref = oracle.build_model(1, 3, "galaxy", n)
+    dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, "galaxy", n))
+    dev.octree.enable_counters(True)
+    dev.octree_force(theta)
+    dev.sync()
+    size, mass = dev.octree.info(dev.stream)
+    ocnt, osize, omass = oracle.octree_step_force(ref, theta, want_counts=True)
+    assert (size, mass) == (osize, omass)
+    assert np.array_equal(dev.octree.read_counters(dev.stream), ocnt)
+    assert maxrel(dev.download().a, ref.a) <= FORCE_TOL[1]
+    dev.close()
+
+
 def test_sharded_octree_torch_path(nb):
     """ShardedOctree (torch tensors' data_ptr() and torch's current stream through the C ABI; every 'rank' rebuilds the
     whole tree and walks it for its own bodies): one rank and two emulated ranks give bitwise the single-context run."""

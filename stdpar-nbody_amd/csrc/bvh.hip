@@ -1409,7 +1409,13 @@ extern "C" int nbody_bvh_create_on(nbody_bvh** out, int dtype, int dim, uint32_t
   NB_ALLOC(t->idx[1], sizeof(uint32_t) * size_t(n));
   NB_ALLOC(t->hist, sizeof(uint32_t) * radix_sort_scratch_words(n));
   NB_ALLOC(t->tmp, tmp_bytes);
-  NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));  // internal nodes + body slots
+  // internal nodes + body slots = level-order indices 0 .. 2 nleafs - 2, one record (one s_load_dwordx16 / x8) each.  No padding
+  // is needed for the sweep's speculative requests: a descent asks for 2 i + 1 only when some lane OPENS entry i, and a body
+  // record (threshold -1, NaN accepts) is never opened; a skip asks for the sibling i + 1 of a left child (i odd, so i + 1 is the
+  // even index on the same level) or for parent + 1 = i / 2 <= i of a right child (the root, i = 0, asks for itself); the jump path
+  // converts a live key (covered < sz, level <= nlevels) and leaves first if the key is past the tree.  Every request stays in
+  // [0, 2 nleafs - 2] (tests: the sweep at theta = 3 accepting the root, n = 2, 3, powers of two — test_gpu_bvh.py).
+  NB_ALLOC(t->node, t->rec_bytes * (size_t(t->nnodes) + size_t(nleafs)));
   NB_ALLOC(t->box, t->tsz * 2 * D * size_t(t->nnodes));
   NB_ALLOC(t->order, sizeof(uint32_t) * (((size_t(n) + 63) / 64 / 8 + 1) * 2 + 8) * 8);  // 8 x (longest range + the largest budget)
   NB_ALLOC(t->order_n, sizeof(uint32_t) * 8);

@@ -116,6 +116,26 @@ def test_smem_pipeline_registers_untouched_in_flight(nb):
     assert not problems, "\n".join(problems[:10])
 
 
+def test_k9_step_program_never_leaves_a_record_request_in_flight(nb):
+    """K9's sweep requests the record behind a skip before it knows whether the walk goes on (round 4), so a request can be in
+    flight when the walk ends and when the jump path asks for another record into the same block; one `s_waitcnt lgkmcnt(0)` in
+    the program text closes each.  Without them a record lands in registers the compiler has handed to something else — the
+    pointers of the kernel's final stores (the abort of round 4).  The checker's two rules (no instruction touches an
+    in-flight range; no request of a hand-written block is in flight at s_endpgm) must hold for all eight instantiations, in double
+    (s_load_dwordx16) and in float (s_load_dwordx8) — and the checker must be ABLE to see the defect: every wait that guards a record
+    block is removed from the parsed program in turn, and each removal must be reported."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    spec = importlib.util.spec_from_file_location("check_smem_pipeline", os.path.join(ROOT, "tools", "check_smem_pipeline.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    kernels, tried, missed = mod.self_test(nb.LIB_PATH)
+    assert kernels == 8, f"{kernels} instantiations of bvh_force_sweep_isa_kernel found, expected 8 (2 precisions x 2 dimensions x counters)"
+    assert tried >= 4 * kernels, f"only {tried} guarding waits found in {kernels} kernels"
+    assert missed == 0, f"{missed} of {tried} removed waits went unreported"
+
+
 def test_no_unpadded_isa_hazards_in_the_code_object(nb):
     """hipcc pads the data hazards of its own instructions, not those inside or at the edge of an asm block (round 3: an asm
     v_readfirstlane_b32 directly behind the compiler's v_mov of its source read the register's previous content in three

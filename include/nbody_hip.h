@@ -75,7 +75,8 @@ typedef struct nbody_state {
  *      a tree used with a stream of another device is refused; nbody_state.tuning is validated (0 or NBODY_TUNING(...)).
  * 2.2: nbody_bvh_read what = 6 and nbody_bvh_opening_thresholds (the opening test as one compare), nbody_all_pairs_pair_rule;
  *      the measured forms that are not shipped (traversal 3 / 4 / 6, octree build 2 / 4) are refused by this library.
- * 2.3: nbody_all_pairs_status; nbody_stream_sync / nbody_download return NBODY_ERR_STATE after a failed K1 chunk hand-off. */
+ * 2.3: nbody_all_pairs_status; nbody_stream_sync / nbody_download return NBODY_ERR_STATE after a failed K1 chunk hand-off;
+ *      nbody_all_pairs_pair_rule decides from the positions' variances, not from their bounding box. */
 #define NBODY_HIP_ABI_VERSION 2003
 int nbody_abi_version(void);
 
@@ -265,13 +266,15 @@ int  nbody_ctx_set_shard(nbody_ctx* ctx, uint32_t first, uint32_t count);
 /* What K1 will launch for this view, e.g. "all_pairs_force_sgpr_kernel<double,3,R=2,JS=8> tile=512 pair=far3/near2"
  * (bench.py stamps its profiles with it). */
 int  nbody_all_pairs_describe(const nbody_state* s, char* out, size_t len);
-/* Which per-pair rounding form K1 (sz >= 32768) takes for this state — a property of the WHOLE system's extent, the same
- * on every rank and for every shard window: *sparse_out = 1 when the bounding box of all sz positions (its volume, area in 2D,
- * through *volume_out if not NULL) is at least 1.7e5 (6.4e4 in 2D); pairs at r^2 >= 4 then drop the eps term of
- * m / (r^3 + eps), which is below an eighth of an ulp there (float: they take m r^-3 from the reciprocal square root alone).
- * 0: the dense rule (always below 32768 bodies).
- * Either form is within 2.5 ulp per term, but one body leaving a compact system can move a run from one to the other between
- * two steps; tests and bitwise A/B runs query the rule in force with this call.  Blocking (one reduction + a 48-byte copy). */
+/* Which per-pair rounding form K1 (sz >= 32768) takes for this state — a property of ALL sz positions, the same on every rank
+ * and for every shard window: *sparse_out = 1 when the volume (area in 2D; through *volume_out if not NULL) of the uniformly
+ * filled box that has the positions' variances, prod_k sqrt(12 var_k), is at least 1.7e5 (6.4e4 in 2D); pairs at r^2 >= 4 then
+ * drop the eps term of m / (r^3 + eps), which is below an eighth of an ulp there (float: they take m r^-3 from the reciprocal
+ * square root alone).  0: the dense rule (always below 32768 bodies).  The moments are summed in a fixed order (same bits on
+ * every rank and in every run).  Until ABI 2.2 the volume was the bounding box's, which a single escaping body inflates at
+ * will: config 2 as written took the sparse rule from its 36th step on with every batch of pairs holding a close one (+ 8.5 %).
+ * Either form is within 2.5 ulp per term, but a system that spreads out moves from one to the other between two steps; tests
+ * and bitwise A/B runs query the rule in force with this call.  Blocking (one reduction + a 16-byte copy). */
 int  nbody_all_pairs_pair_rule(const nbody_state* s, void* stream, int* sparse_out, double* volume_out);
 
 /* ---- the collective: per-step all-gather of position shards (multi-GPU all-pairs; no reference counterpart) ------

@@ -67,7 +67,7 @@ static ap_config ap_config_of(const nbody_state* s) {
 template <typename T, int D, int R, int JS>
 __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                                  T* __restrict__ a, T c, uint32_t sz, uint32_t first,
-                                                                 uint32_t count, const unsigned long long* __restrict__ ext) {
+                                                                 uint32_t count, const k1_rule* __restrict__ rule) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kWaves / JS;    // target groups per block
   constexpr int TB  = TG * 64 * R;    // targets per block
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void all_pairs_force_kernel(const T* __rest
 
   const uint32_t ntiles = (sz + kTileJ - 1) / kTileJ;
   const pair_consts<T> pc;
-  const bool ffar = ap_far_mode<D>(ext);
+  const bool ffar = ap_far_mode(rule);
 
   // register staging of one tile: LPT records per lane
   rec_t stage[LPT];
@@ -191,51 +191,99 @@ __global__ __launch_bounds__(kBlock) void pack_sources_kernel(const T* __restric
   out[j] = r;
 }
 
-// bounding box of all sz positions as order-preserving keys (common.hpp: ext_key), at most 256 blocks
-template <typename T, int D>
-__global__ __launch_bounds__(kBlock) void extent_kernel(const T* __restrict__ x, uint32_t sz, unsigned long long* __restrict__ ext) {
+// What a K1 launch needs done first, in ONE launch (rounds 2-4: a memset, the extent kernel, the pack kernel and another memset —
+// four dependent launches, 20 us of a 73 us call at n = 8192):
+//   PACK     the (x, m) records of the scalar-stream form, as pack_sources_kernel above;
+//   MOMENTS  the first and second moments of all sz positions, relative to body 0 (so that a system far from the origin does not
+//            cancel), summed per block in a fixed order; the LAST block to deliver (a ticket) adds the blocks' sums in index order
+//            and writes the rule (common.hpp: k1_rule) — the same bits whichever block comes last;
+//   and the last block also hands the turn of every target group back to chunk 0 (the words K1's chunks pass around).
+// One block per 256 bodies of the padded set; the ticket returns to 0, so a recorded launch can be replayed.
+template <typename T, int D, bool PACK, bool MOMENTS>
+__global__ __launch_bounds__(kBlock) void k1_prepare_kernel(const T* __restrict__ m, const T* __restrict__ x, src_rec<T, D>* __restrict__ out,
+                                                            uint32_t sz, uint32_t padded, k1_rule* rule, double* partial,
+                                                            uint32_t* turn, uint32_t turn_words) {
+  const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+  T p[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) p[k] = j < sz ? x[uint64_t(j) * D + k] : T(0);
+  if constexpr (PACK) {
+    if (j < padded) {
+      src_rec<T, D> r;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) r.p[k] = k < D ? p[k < D ? k : 0] : T(0);
+      r.m    = j < sz ? m[j] : T(0);
+      out[j] = r;
+    }
+  }
   __shared__ double red[2 * D][kWaves];
-  double lo[D], hi[D];
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    lo[k] = double(x[k]);  // body 0: sz >= 1
-    hi[k] = lo[k];
-  }
-  for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < sz; j += gridDim.x * kBlock) {
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-      const double v = double(x[uint64_t(j) * D + k]);
-      lo[k]          = v < lo[k] ? v : lo[k];
-      hi[k]          = v > hi[k] ? v : hi[k];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < D; ++k) {
-    for (int off = 32; off > 0; off >>= 1) {
-      const double ol = __shfl_xor(lo[k], off, 64), oh = __shfl_xor(hi[k], off, 64);
-      lo[k] = ol < lo[k] ? ol : lo[k];
-      hi[k] = oh > hi[k] ? oh : hi[k];
-    }
-  }
+  __shared__ bool last_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (lane == 0) {
+  if constexpr (MOMENTS) {
+    double s1[D], s2[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-      red[k][wave]     = lo[k];
-      red[D + k][wave] = hi[k];
+      const double d = j < sz ? double(p[k]) - double(x[k]) : 0.0;  // relative to body 0 (sz >= 1)
+      s1[k] = d;
+      s2[k] = d * d;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k)
+      for (int off = 32; off > 0; off >>= 1) {  // butterfly: every lane ends with the same sum, formed in the same order
+        s1[k] += __shfl_xor(s1[k], off, 64);
+        s2[k] += __shfl_xor(s2[k], off, 64);
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < D; ++k) {
+        red[k][wave]     = s1[k];
+        red[D + k][wave] = s2[k];
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * D) {
+      double v = red[threadIdx.x][0];
+      for (int w = 1; w < kWaves; ++w) v += red[threadIdx.x][w];
+      __hip_atomic_store(partial + size_t(blockIdx.x) * (2 * D) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+  // the ticket: the block that draws the last number knows that every other block's stores are out
+  __threadfence();
   __syncthreads();
-  if (threadIdx.x < 2 * D) {
-    const bool is_max = threadIdx.x >= D;
-    double v = red[threadIdx.x][0];
-    for (int w = 1; w < kWaves; ++w) {
-      const double o = red[threadIdx.x][w];
-      v = is_max ? (o > v ? o : v) : (o < v ? o : v);
+  if (threadIdx.x == 0) last_s = atomicAdd(&rule->ticket, 1u) == gridDim.x - 1u;
+  __syncthreads();
+  if (!last_s) return;
+  __threadfence();
+  if constexpr (MOMENTS) {
+    double acc = 0.0;  // thread t: moment t % (2 D) of the blocks t / (2 D), t / (2 D) + G, ... in ascending order (G groups)
+    constexpr int G = kBlock / (2 * D);
+    const int q = threadIdx.x % (2 * D), g = threadIdx.x / (2 * D);
+    if (g < G)
+#pragma unroll 1
+      for (uint32_t b = uint32_t(g); b < gridDim.x; b += G)
+        acc += __hip_atomic_load(partial + size_t(b) * (2 * D) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __shared__ double fin[kBlock];
+    fin[threadIdx.x] = g < G ? acc : 0.0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double vol = 1.0;
+#pragma unroll 1
+      for (int k = 0; k < D; ++k) {
+        double m1 = 0.0, m2 = 0.0;
+#pragma unroll 1
+        for (int gg = 0; gg < G; ++gg) {  // groups in index order (not unrolled: 2 D x 42 loads in flight took 260 VGPRs)
+          m1 += fin[gg * (2 * D) + k];
+          m2 += fin[gg * (2 * D) + D + k];
+        }
+        const double mean = m1 / double(sz), var = m2 / double(sz) - mean * mean;
+        vol *= var > 0.0 ? __builtin_sqrt(12.0 * var) : 0.0;
+      }
+      rule->volume = vol;
+      rule->sparse = vol >= kFarMinVolume<D> ? 1u : 0u;
     }
-    const unsigned long long key = is_max ? ~ext_key(v) : ext_key(v);
-    atomicMin(&ext[threadIdx.x], key);
   }
+  for (uint32_t w = threadIdx.x; w < turn_words; w += kBlock) turn[w] = 0u;  // chunk 0 holds every turn
+  if (threadIdx.x == 0) __hip_atomic_store(&rule->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int JS>
@@ -281,7 +329,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
                                                                                    const T* __restrict__ x, T* a, T c, uint32_t sz,
                                                                                    uint32_t first, uint32_t count,
                                                                                    uint32_t tiles_per_chunk, k1_handoff h,
-                                                                                   const unsigned long long* __restrict__ ext) {
+                                                                                   const k1_rule* __restrict__ rule) {
   using rec_t = src_rec<T, D>;
   constexpr int TG  = kSgprWaves<JS> / JS;
   constexpr int TB  = TG * 64 * R;
@@ -309,7 +357,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   const uint32_t t0     = blockIdx.y * tiles_per_chunk;
   const uint32_t t1     = min(ntiles, t0 + tiles_per_chunk);
   const pair_consts<T> pc;
-  const bool ffar       = ap_far_mode<D>(ext);
+  const bool ffar       = ap_far_mode(rule);
   const uint32_t nsteps = (t1 - t0) * SUB;  // sources this wave visits: its SUB-record slice of every tile, in tile order
   constexpr int U = 64 / int(sizeof(rec_t));  // records per 64-byte batch (2 in f64, 4 in f32); SUB % (2 * U) == 0
   struct batch_t {
@@ -491,10 +539,10 @@ int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out) {
   }
   void* fresh = nullptr;
   NB_HIP(hipMalloc(&fresh, bytes));  // on the stream's device: the caller holds a device_guard
-  if (which == 4) {                  // the status block starts clean and is never re-allocated (fixed size)
+  if (which == 4 || which == 3) {    // the status block and the rule's ticket start at zero
     if (hipError_t e = hipMemset(fresh, 0, bytes); e != hipSuccess) {
       (void)hipFree(fresh);
-      return hip_fail(e, "hipMemset(k1_status)", __FILE__, __LINE__);
+      return hip_fail(e, "hipMemset(K1 scratch)", __FILE__, __LINE__);
     }
   }
   if (slot->buf[which].ptr) slot->retired.push_back(slot->buf[which].ptr);
@@ -611,20 +659,36 @@ int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out) {
   return rc;
 }
 
-// The bounding box of the whole system for ap_far_mode, stream-ordered before K1; nullptr ("dense") below kFarMinBodies.
+// Bytes of scratch buffer 3 for a system of sz bodies: the rule, then one row of 2 D partial sums per prepare block.
+static size_t ap_rule_bytes(uint32_t sz, int dim) {
+  const size_t padded = (size_t(sz) + kTileJ - 1) / kTileJ * kTileJ;
+  return 32 + sizeof(double) * 2 * size_t(dim) * (padded / kBlock);
+}
+
+// Everything a K1 launch needs done first, queued as ONE launch (k1_prepare_kernel): the packed records (pack: the scalar-stream
+// form), the pair rule of the whole system (sz >= kFarMinBodies; nullptr = "dense" below) and the turn words handed back to chunk 0.
 template <typename T, int D>
-static int ap_extent(const nbody_state* s, hipStream_t st, const unsigned long long** out) {
-  *out = nullptr;
-  if (s->sz < kFarMinBodies) return NBODY_OK;
+static int ap_prepare(const nbody_state* s, hipStream_t st, bool pack, src_rec<T, D>** packed_out, const k1_rule** rule_out,
+                      uint32_t* turn, size_t turn_words) {
+  const uint32_t padded = (s->sz + kTileJ - 1) / kTileJ * kTileJ;
+  const bool moments    = s->sz >= kFarMinBodies;
+  void* scratch         = nullptr;
+  if (pack)
+    if (int r = ap_scratch_get(st, 0, 4 * sizeof(T) * size_t(padded), &scratch)) return r;
   void* q = nullptr;
-  if (int r = ap_scratch_get(st, 3, 64, &q)) return r;
-  NB_HIP(hipMemsetAsync(q, 0xFF, 2 * D * sizeof(unsigned long long), st));
-  uint32_t blocks = (s->sz + kBlock - 1) / kBlock;
-  if (blocks > 256) blocks = 256;
-  hipLaunchKernelGGL((extent_kernel<T, D>), dim3(blocks), dim3(kBlock), 0, st, static_cast<const T*>(s->x), s->sz,
-                     static_cast<unsigned long long*>(q));
+  if (int r = ap_scratch_get(st, 3, ap_rule_bytes(s->sz, D), &q)) return r;  // (the ticket lives there even without moments)
+  auto* rule    = static_cast<k1_rule*>(q);
+  auto* partial = reinterpret_cast<double*>(static_cast<char*>(q) + 32);
+  auto* out     = static_cast<src_rec<T, D>*>(scratch);
+  const dim3 grid(padded / kBlock), block(kBlock);
+  const T *m = static_cast<const T*>(s->m), *x = static_cast<const T*>(s->x);
+  const uint32_t words = uint32_t(turn_words);
+  if (pack && moments) hipLaunchKernelGGL((k1_prepare_kernel<T, D, true, true>), grid, block, 0, st, m, x, out, s->sz, padded, rule, partial, turn, words);
+  else if (pack) hipLaunchKernelGGL((k1_prepare_kernel<T, D, true, false>), grid, block, 0, st, m, x, out, s->sz, padded, rule, partial, turn, words);
+  else if (moments) hipLaunchKernelGGL((k1_prepare_kernel<T, D, false, true>), grid, block, 0, st, m, x, out, s->sz, padded, rule, partial, turn, words);
   NB_HIP(hipGetLastError());
-  *out = static_cast<const unsigned long long*>(q);
+  if (packed_out) *packed_out = out;
+  *rule_out = moments ? rule : nullptr;
   return NBODY_OK;
 }
 
@@ -651,15 +715,12 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
     if (const char* e = experiment_env("NBODY_K1_TURN_SPINS")) h.spins = uint32_t(strtoul(e, nullptr, 10));
     if (const char* e = experiment_env("NBODY_K1_HANDOFF_DELAY")) h.delay = uint32_t(strtoul(e, nullptr, 10));
   }
-  const unsigned long long* ext = nullptr;
-  if (int r = ap_extent<T, D>(s, st, &ext)) return r;
-  void* scratch = nullptr;
-  if (int r = ap_pack_sources(s, st, &scratch)) return r;
-  auto* packed = static_cast<src_rec<T, D>*>(scratch);
-  if (h.turn) NB_HIP(hipMemsetAsync(h.turn, 0, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), st));  // chunk 0 holds the turn
+  src_rec<T, D>* packed = nullptr;
+  const k1_rule* rule   = nullptr;
+  if (int r = ap_prepare<T, D>(s, st, true, &packed, &rule, h.turn, h.turn ? sgpr_turn_words<R, JS>(s->count) : 0)) return r;
   hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
                      packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
-                     plan.tiles_per_chunk, h, ext);
+                     plan.tiles_per_chunk, h, rule);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -669,10 +730,10 @@ static int launch_all_pairs(const nbody_state* s, hipStream_t st) {
   constexpr int TB = (kWaves / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  const unsigned long long* ext = nullptr;  // the same per-pair rule as the scalar-stream form (bitwise the same result)
-  if (int r = ap_extent<T, D>(s, st, &ext)) return r;
+  const k1_rule* rule = nullptr;  // the same per-pair rule as the scalar-stream form (bitwise the same result)
+  if (int r = ap_prepare<T, D>(s, st, false, nullptr, &rule, nullptr, 0)) return r;
   hipLaunchKernelGGL((all_pairs_force_kernel<T, D, R, JS>), dim3(blocks), dim3(kBlock), 0, st, static_cast<const T*>(s->m),
-                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, ext);
+                     static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count, rule);
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -738,8 +799,7 @@ int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
   const size_t tsz    = s->dtype == NBODY_F32 ? 4 : 8;
   const size_t padded = (size_t(s->sz) + kTileJ - 1) / kTileJ * kTileJ;
   if (int r = ap_scratch_get(st, 0, 4 * tsz * padded, &q)) return r;
-  if (s->sz >= kFarMinBodies)
-    if (int r = ap_scratch_get(st, 3, 64, &q)) return r;
+  if (int r = ap_scratch_get(st, 3, ap_rule_bytes(s->sz, s->dim), &q)) return r;
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using T = typename decltype(tg)::type;
     k1_plan p;
@@ -1112,13 +1172,14 @@ extern "C" int nbody_all_pairs_pair_rule(const nbody_state* s, void* stream, int
   return dispatch(s->dtype, s->dim, [&](auto tg) {
     using T         = typename decltype(tg)::type;
     constexpr int D = decltype(tg)::dim;
-    const unsigned long long* ext = nullptr;
-    if (int r = ap_extent<T, D>(s, as_stream(stream), &ext)) return r;
-    if (ext == nullptr) return int(NBODY_OK);  // below kFarMinBodies: the dense rule by definition
-    unsigned long long host[2 * D];
-    NB_HIP(hipMemcpyAsync(host, ext, sizeof host, hipMemcpyDeviceToHost, as_stream(stream)));
+    const k1_rule* rule = nullptr;
+    if (int r = ap_prepare<T, D>(s, as_stream(stream), false, nullptr, &rule, nullptr, 0)) return r;
+    if (rule == nullptr) return int(NBODY_OK);  // below kFarMinBodies: the dense rule by definition
+    k1_rule host;
+    NB_HIP(hipMemcpyAsync(&host, rule, sizeof host, hipMemcpyDeviceToHost, as_stream(stream)));
     NB_HIP(hipStreamSynchronize(as_stream(stream)));
-    *sparse_out = ap_far_rule<D>(host, volume_out) ? 1 : 0;
+    *sparse_out = host.sparse ? 1 : 0;
+    if (volume_out) *volume_out = host.volume;
     return int(NBODY_OK);
   });
 }

@@ -460,33 +460,30 @@ __device__ __forceinline__ void pair_batch(T (&acc)[R][D], const T (&xi)[R][D], 
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
-// ---- the system's bounding box, for ap_far_mode -------------------------------------------------------------------
-// Coordinates are reduced with integer atomicMin on order-preserving keys (a double's bits, sign-flipped): order-free, so
-// the result is the same whatever the launch shape.  ext[k] = key(min_k), ext[D + k] = ~key(max_k): all six are minima and
-// one memset of 0xFF initialises them.
-__host__ __device__ inline unsigned long long ext_key(double v) {
-  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
-  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
-}
-__host__ __device__ inline double ext_value(unsigned long long key) {
-  const unsigned long long b = (key >> 63) ? (key ^ 0x8000000000000000ull) : ~key;
-  return __builtin_bit_cast(double, b);
-}
+// ---- which per-pair rule a launch takes: ap_far_mode ---------------------------------------------------------------------
+// Sparse iff a batch of 256 pairs rarely holds one closer than 2.  For bodies spread with density rho (normalised) the chance that a
+// random pair is that close is (32 pi / 3) * integral(rho^2); for a uniformly filled box that integral is 1 / V, and the rule asks
+// for 256 * (4/3 pi 8) / V < 0.05 (256 * 4 pi / A in 2D).  V is NOT the bounding box (rounds 3-4): one escaper inflates that at will
+// — config 2 as written (the uniform cube, dt = 0.1) ejects a few bodies at ten times the bulk's speed, after 35 steps the box says
+// "sparse" while 98 % of the bodies sit in a cube of side 7 and EVERY batch holds a close pair, and the sparse rule's mixed path
+// made the last 65 of its 100 steps 8.5 % slower (profiles/r05/config2_state_probe.txt).  V is the volume of the uniformly
+// filled box with the positions' VARIANCES: side_k = sqrt(12 var_k) — the same number for a uniform box, 0.94 of the Gaussian's
+// 1 / integral(rho^2), and a few escapers move it by their share of the mass, not by their distance.  Real systems are clumpier
+// than their variances (the galaxy's two discs: 6 % of the batches hold a close pair at V = 3e6) — the rule only has to tell a
+// cube from a galaxy.  The moments are summed in double in a FIXED order (per block of 256 bodies, then over the blocks in index
+// order by the last block to finish), from all sz positions whatever the shard window: every rank, every window and every run
+// computes the same bits, so the rule — which fixes the rounding of every pair — is a function of the state alone.
+struct k1_rule {
+  double volume;    // prod_k sqrt(12 var_k)
+  uint32_t sparse;  // volume >= threshold
+  uint32_t ticket;  // blocks of the running prepare launch that have delivered their partial sums (0 between launches)
+};
 constexpr uint32_t kFarMinBodies = 32768;  // below this the rule is "dense" by definition (from sz alone: nothing is measured)
-// Sparse iff a batch of 256 pairs rarely holds one closer than 2: with the bodies spread over the box of volume V the expected
-// number of such pairs per batch is 256 * (4/3 pi 8) / V (256 * 4 pi / A in 2D); the rule asks for < 0.05.  Real systems are
-// clumpier than their box (the galaxy: 6 % of the batches at V = 4e6) — the rule only has to tell a unit cube from a galaxy.
 template <int D>
-__host__ __device__ inline bool ap_far_rule(const unsigned long long* ext, double* volume = nullptr) {  // the rule itself (host: nbody_all_pairs_pair_rule)
-  double vol = 1.0;
-  for (int k = 0; k < D; ++k) vol *= ext_value(~ext[D + k]) - ext_value(ext[k]);
-  if (volume) *volume = vol;
-  return vol >= (D == 3 ? 1.7e5 : 6.4e4);
-}
-template <int D>
-__device__ __forceinline__ bool ap_far_mode(const unsigned long long* __restrict__ ext) {
-  if (ext == nullptr) return false;
-  return __builtin_amdgcn_readfirstlane(int(ap_far_rule<D>(ext))) != 0;
+constexpr double kFarMinVolume = D == 3 ? 1.7e5 : 6.4e4;
+__device__ __forceinline__ bool ap_far_mode(const k1_rule* __restrict__ rule) {
+  if (rule == nullptr) return false;
+  return __builtin_amdgcn_readfirstlane(int(rule->sparse)) != 0;
 }
 
 // ---- scalar-stream helpers (K1's default form, the energies) ------------------------------------------------
@@ -518,7 +515,7 @@ inline int check_tuning(int split, int tpt, int path) {
 // all_pairs.hip: per-(device, stream) packed-source scratch of the scalar-stream K1 (reserved by nbody_create, freed by nbody_destroy)
 int ap_scratch_reserve(hipStream_t st, const nbody_state* view);
 void ap_scratch_release(hipStream_t st);
-int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 turn words, 2 energies, 3 bounding-box keys, 4 K1 hand-off status
+int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 turn words, 2 energies, 3 the pair rule (k1_rule + the blocks' partial moments), 4 K1 hand-off status
 int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear);  // waits for the stream; NBODY_ERR_STATE while a K1 hand-off failure is recorded
 int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk);

@@ -620,8 +620,20 @@ def test_sparse_system_pair_rules_with_planted_pairs(nb, oracle, dim):
     sparse, vol = nb.all_pairs_pair_rule(dev.state(), dev.stream)   # the rule in force is a property of the system's extent
     assert sparse and vol >= (1.7e5 if dim == 3 else 6.4e4), (sparse, vol)
     assert nb.all_pairs_pair_rule(dev.state(100, 5000), dev.stream) == (sparse, vol)   # ... the same for every shard window
-    dense = nb.DeviceSystem.from_host(nb.build_model(nb.F64, dim, "uniform", n))      # the unit cube: the dense rule
+    hd = nb.build_model(nb.F64, dim, "uniform", n)                                     # the unit cube: the dense rule
+    dense = nb.DeviceSystem.from_host(hd)
     assert nb.all_pairs_pair_rule(dense.state(), dense.stream)[0] is False
+    dense.close()
+    # ... and the cube with a few escapers far outside (what config 2 as written becomes: close encounters eject bodies at ten
+    # times the bulk's speed): the bounding box would say "sparse" (rounds 3-4: + 8.5 % on config 2), the variances do not
+    hd.x[rng.integers(0, n, 40)] *= 400.0
+    dense = nb.DeviceSystem.from_host(hd)
+    sp, v = nb.all_pairs_pair_rule(dense.state(), dense.stream)
+    assert sp is False and np.prod(np.ptp(hd.x, axis=0)) > (1.7e5 if dim == 3 else 6.4e4) > v, (sp, v, np.ptp(hd.x, axis=0))
+    side_eff = np.sqrt(12.0 * hd.x.astype(np.float64).var(axis=0))
+    assert abs(v - np.prod(side_eff)) <= 1e-9 * v, (v, side_eff)                       # the documented quantity: prod sqrt(12 var_k)
+    again = nb.all_pairs_pair_rule(dense.state(7, 1000), dense.stream)
+    assert again == (sp, v)                                                            # the same BITS from another window, another launch
     dense.close()
     dev.all_pairs_force()
     dev.sync()

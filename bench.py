@@ -30,6 +30,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 FP64_VECTOR_PEAK_TFLOPS = 78.6   # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP32_VECTOR_PEAK_TFLOPS = 157.3  # the same lanes at 2 x 32 bits
 FLOP_PER_INTERACTION = 20        # D=3: 3 sub + 5 r2 + 2 (sqrt, *r2) + 1 (+eps) + 3 (m*d) + 3 (/) + 3 (acc)
 
 
@@ -174,6 +175,139 @@ def committed_evidence(world, n, kernel_desc):
     return None, None
 
 
+def source_sha(*files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "stdpar-nbody_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def committed_config_evidence(name, sha):
+    """The newest committed profiles/r*/pmc_<name>.json (tools/pmc_configs.py: rocprofv3 --pmc, separate passes, one dispatch of the
+    config's dominant kernel) whose source stamp matches the library this run loaded; None otherwise."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "pmc_%s.json" % name)), reverse=True):
+        try:
+            c = json.load(open(path))
+        except Exception:
+            continue
+        if c.get("source_sha") != sha:
+            continue
+        cycles = c["GRBM_GUI_ACTIVE"] / 8.0                                  # summed over the 8 XCDs
+        busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024)              # quad-cycles -> cycles, 1024 SIMDs
+        lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0) if c.get("SQ_THREAD_CYCLES_VALU") else None
+        traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+        return {"source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, separate passes; stamped with this library's source hash)",
+                "kernel": c.get("kernel"), "valu_busy_frac": busy, "valu_lanes_active_frac": lanes,
+                "valu_issue_frac": busy * lanes if lanes is not None else None,
+                "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"),
+                "hbm_traffic_bytes_per_launch": traffic, "duration_ms_in_profiled_pass": c.get("duration_ns", 0) / 1e6 or None}
+    return None
+
+
+def other_configs(nb, torch):
+    """BASELINE.json configs[1..3] on this GPU, after the headline's clock has stopped (the reference's own matrix, ci/benchmark:63-98,
+    runs its algorithms back to back the same way).  Each as the CLI runs it: the step recorded once and replayed (host/drivers.hpp),
+    10 warm-up steps and then the timed ones; the dominant kernel's average launch time from HIP events on the context's stream
+    around the call that launches it, in further steps of the same evolving system."""
+    out = []
+
+    def events_around(dev, fn, reps, between=None):
+        st = torch.cuda.ExternalStream(dev.stream)
+        pairs = []
+        for _ in range(reps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(st)
+            fn()
+            b.record(st)
+            pairs.append((a, b))
+            if between:
+                between()
+        dev.sync()
+        return sum(a.elapsed_time(b) for a, b in pairs) / reps
+
+    def replayed(dev, record, steps, warm=10):
+        g = nb.StepGraph(dev, record)
+        for _ in range(warm):
+            g.launch()
+        dev.sync()
+        t0 = time.perf_counter()
+        for _ in range(steps - warm):
+            g.launch()
+        dev.sync()
+        ms = (time.perf_counter() - t0) / (steps - warm) * 1e3
+        g.close()
+        return ms
+
+    # configs[1]: all-pairs 3D double, -n 65536 -s 100 (no workload flag: the reference's default, uniform)
+    n = 65536
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "uniform", n))
+    dev.all_pairs_force(); dev.sync()
+    ms = replayed(dev, lambda: (dev.all_pairs_force(), dev.accelerate_step()), 100)
+    k_ms = events_around(dev, dev.all_pairs_force, 20, between=dev.accelerate_step)
+    desc = nb.describe_all_pairs(dev.state())
+    hand = nb.all_pairs_status(dev.stream)
+    tf = FLOP_PER_INTERACTION * n * (n - 1) / (k_ms * 1e-3) / 1e12
+    out.append({"workload": "all-pairs 3D double, -n 65536 -s 100, uniform (the default workload), 1 GPU: steps 11-100 of the recorded step",
+                "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3), "kernel": desc, "avg_kernel_ms": k_ms,
+                "avg_kernel_how": "HIP events around nbody_all_pairs_force (the pre-pass launch, ~6 us, + K1) in steps 101-120",
+                "bound": "valu_fp64", "achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VECTOR_PEAK_TFLOPS,
+                "handoff": {"failed": hand["failed"], "waves_that_waited": hand["waits"], "polls": hand["polls"]}})
+    dev.close()
+
+    # configs[2]: all-pairs-collapsed 3D float, -n 262144 (uniform), -s 20
+    n = 262144
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F32, 3, "uniform", n))
+    dev.all_pairs_collapsed_force(); dev.sync()
+    ms = replayed(dev, lambda: (dev.all_pairs_collapsed_force(), dev.accelerate_step()), 20)
+    k_ms = events_around(dev, dev.all_pairs_collapsed_force, 10, between=dev.accelerate_step)
+    tf = FLOP_PER_INTERACTION * n * (n - 1) / (k_ms * 1e-3) / 1e12
+    ev = committed_config_evidence("k2_config3", source_sha("all_pairs.hip", "common.hpp"))
+    out.append({"workload": "all-pairs-collapsed 3D float, -n 262144 -s 20, uniform, 1 GPU: steps 11-20 of the recorded step",
+                "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3), "kernel": "all_pairs_collapsed_kernel<float,3> (+ collapsed_reset_kernel)",
+                "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_all_pairs_collapsed_force in steps 21-30",
+                "bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_PEAK_TFLOPS,
+                "rocprof": ev})
+    dev.close()
+
+    # configs[3]: bvh 3D double, -n 1000000 --workload galaxy (theta 0.5), -s 20
+    n, theta = 1000000, 0.5
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "galaxy", n))
+    dev.bvh_force(theta); dev.accelerate_step(); dev.sync()
+    ms = replayed(dev, lambda: (dev.bvh_force(theta), dev.accelerate_step()), 20)
+    st, t = dev.state(), dev.bvh
+    walk = lambda: t.compute_force(st, theta, dev.stream)
+    rest = lambda: (dev.accelerate_step(), t.bounding_box(st, dev.stream), t.hilbert_sort(st, dev.stream), t.build_tree(st, dev.stream))
+    rest()
+    k_ms = events_around(dev, walk, 10, between=rest)
+    t.enable_counters(True)      # one counted traversal of the state the last timed one saw: node tests, leaf visits, accepted entries
+    walk(); dev.sync()
+    cnt = t.read(5, dev.stream).astype("float64").sum(axis=0)
+    t.enable_counters(False)
+    node_tests, leaf_visits, terms = cnt[0], cnt[1], cnt[2] + cnt[3]
+    cold_bytes = node_tests * 40.0 + leaf_visits * 64.0      # SURVEY 8(d): 40 B per node test (monopole + width), 2 x 32 B per leaf
+    ev = committed_config_evidence("k9_config4", source_sha("bvh.hip", "common.hpp"))
+    out.append({"workload": "bvh 3D double, -n 1000000 -s 20 --workload galaxy --theta 0.5, 1 GPU: steps 11-20 of the recorded step",
+                "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3),
+                "kernel": "bvh_force_sweep_isa_kernel<double,3> (+ bvh_items_kernel; K4-K8 and K3 are the rest of the step)",
+                "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_bvh_compute_force in steps 21-30 of the evolving system",
+                "bound": "valu_issue", "node_tests_per_s": node_tests / (k_ms * 1e-3), "node_tests_per_body": node_tests / n,
+                "force_terms_per_body": terms / n,
+                "frac": ev["valu_issue_frac"] if ev else None,
+                "frac_is": "VALU busy x lanes active (rocprofv3 PMC of this kernel): the share of the vector issue slots that do a body's work; "
+                           "null unless a committed PMC summary carries this library's source hash",
+                "rocprof": ev,
+                "not_the_bound": {"hbm_cold_bytes_per_s": cold_bytes / (k_ms * 1e-3), "hbm_peak_bytes_per_s": 8.0e12,
+                                  "why": "SURVEY 8(d) prices K9 as if every node test fetched its 40 B from HBM: that is %.1f TB/s here, above "
+                                         "the 8 TB/s peak.  The sweep reads a record ONCE PER WAVE through the scalar cache (64 bodies share "
+                                         "it) and the tree (92 MB) lives in L2 / MALL: measured HBM traffic is ~1.3 GB per traversal, 2-3 %% "
+                                         "of peak.  What bounds the kernel is instruction issue: ~40 instructions per step of a wave, of which "
+                                         "the lanes of a wave use about half" % (cold_bytes / (k_ms * 1e-3) / 1e12)}})
+    dev.close()
+    return out
+
+
 def visible_gpus():
     """Number of HIP devices this process could use, without creating a HIP context (torch.cuda.device_count() reads the
     driver's device list only)."""
@@ -253,6 +387,7 @@ def main():
     ap.add_argument("--bodies", dest="n", type=int, default=1 << 20,
                     help="bodies (default 2^20, the BASELINE.json metric config); `--n` would collide with torchrun option prefixes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip BASELINE.json configs[1..3] (the `configs` list of the line)")
     ap.add_argument("--exchange", choices=("nbody", "torch"), default="nbody",
                     help="the per-step all-gather of positions: nbody = the library's own collective (nbody_allgather_positions, "
                          "RCCL behind the C ABI; what the metric is about, and the only form that earns a normal line); torch = "
@@ -311,7 +446,8 @@ def main():
     # Fault injection for the tests of the failure exits below (tests/test_gpu_multi.py): "<kind>:<rank>" with kind in
     # comm_create (the communicator cannot be created on that rank), stale_exchange (that rank's exchange delivers nothing from
     # the start: it takes part in the collective and throws the result away), stale_late (… from the first timed step on: only
-    # the end-of-run checks can see it), corrupt_a (one acceleration row of that rank is altered before the bitwise check).
+    # the end-of-run checks can see it), corrupt_a (one acceleration row of that rank is altered before the bitwise check), nan_a (one
+    # component outside the sampled windows becomes NaN: what a failed K1 chunk hand-off leaves behind).
     fault_kind, _, fault_rank = os.environ.get("NBODY_BENCH_FAULT", "").partition(":")
     fault = fault_kind if fault_kind and int(fault_rank or 0) == rank else None
 
@@ -460,6 +596,17 @@ def main():
         torch.cuda.synchronize()
         if fault == "corrupt_a":
             sim.a[sim.count // 2] += 1e-9
+        if fault == "nan_a":
+            sim.a[sim.count // 3, 1] = float("nan")
+        # a failed chunk hand-off of K1 on ANY rank (sticky status word of its stream; its rows are NaN) voids the run, and so
+        # does a NaN in any rank's accelerations whatever its origin: the windows below only sample the shards
+        hand = nb.all_pairs_status(sim._stream(), check=False)
+        bad = torch.tensor([1 if (hand["failed"] or bool(torch.isnan(sim.a).any().item())) else 0], dtype=torch.int32, device=red_dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) != 0:
+            fail_all("bitwise_vs_single: a rank holds NaN accelerations or reports a failed K1 chunk hand-off (this rank: %s): the run is void"
+                     % ("hand-off failed at block %d chunk %d" % (hand["block"], hand["chunk"]) if hand["failed"] else
+                        ("NaN in a" if bool(torch.isnan(sim.a).any().item()) else "clean")))
         scratch = torch.empty((WIN, 3), dtype=sim.a.dtype, device=dev)
         checked, mismatch, k1_failed, window_desc = [], [], "", None
         for p, (pf, pe) in enumerate(sim.shards):
@@ -493,6 +640,19 @@ def main():
                    "launch_shapes": {"rank_shard": kernel_desc, "window": window_desc},
                    "how": "after the timed steps every rank recomputed K1 on its shard; rank 0 recomputed a window in the middle of "
                           "each rank's shard from its own x and compared the rows bit for bit"}
+
+    # K1's chunk hand-off over the whole run of this rank's stream: failed must be False; waits / polls say how often a block had to
+    # wait for its turn (normally never)
+    hand = nb.all_pairs_status(sim._stream(), check=False)
+    if hand["failed"] and not use_dist:
+        print("bench.py: K1 chunk hand-off failed (block %d, chunk %d): no result" % (hand["block"], hand["chunk"]), file=sys.stderr)
+        os._exit(3)
+    handoff = {"failed": hand["failed"], "waves_that_waited": hand["waits"], "polls": hand["polls"]}
+    if use_dist:
+        mine = torch.tensor([hand["waits"], hand["polls"]], dtype=torch.int64, device=red_dev)
+        allh = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allh, mine)
+        handoff = {"failed": False, "waves_that_waited": [int(t[0]) for t in allh], "polls": [int(t[1]) for t in allh], "by": "rank"}
 
     if rank == 0:
         value = n * args.steps / elapsed
@@ -529,10 +689,16 @@ def main():
                          "frac_at_measured_clock": (achieved / (FP64_VECTOR_PEAK_TFLOPS * tele["sclk_mhz_mean"] / 2400.0)
                                                     if tele else None),
                          "rocprof": evidence,
+                         "handoff": handoff,
                          "note": "north_star forbids MFMA for this path; bound is the FP64 vector pipe "
                                  "(20 algorithmic flop per ordered pair, SURVEY 8d); traffic/rocprof are null unless a "
                                  "committed PMC summary carries this run's kernel description and source hash"},
         }
+        if world == 1 and not args.no_other_configs:
+            try:   # BASELINE.json configs[1..3], after the headline's clock has stopped: reported extras, never lose the line over them
+                out["configs"] = other_configs(nb, torch)
+            except Exception as ex:
+                out["configs"] = [{"workload": "configs[1..3]", "failed": str(ex)}]
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(n, hs)

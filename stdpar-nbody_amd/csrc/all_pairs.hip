@@ -324,7 +324,7 @@ struct k1_handoff {
   uint32_t spins;     // polls before a waiting wave gives up (kTurnSpins; lowered only by the experiments build's tests)
   uint32_t delay;     // s_sleep(127) rounds before a turn is passed on (0; the experiments build's tests make successors wait)
 };
-template <typename T, int D, int R, int JS>
+template <typename T, int D, int R, int JS, int RULE = 0>
 __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
                                                                                    const T* __restrict__ x, T* a, T c, uint32_t sz,
                                                                                    uint32_t first, uint32_t count,
@@ -386,7 +386,9 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
     }
     swait(A, acc[0][0]);  // nothing in flight when the wave goes on
   };
-  if (ffar) run(std::true_type{});  // two copies of the loop: inside ONE loop hipcc hoists the rules' common head above the branch
+  if constexpr (RULE == 1) run(std::false_type{});      // (experiments: one rule per instantiation, forced from the host)
+  else if constexpr (RULE == 2) run(std::true_type{});
+  else if (ffar) run(std::true_type{});  // two copies of the loop: inside ONE loop hipcc hoists the rules' common head above the branch
   else run(std::false_type{});
   if constexpr (JS > 1) {
     if (jpart > 0) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   const uint32_t y = blockIdx.y, last = gridDim.y - 1u;
   uint32_t* const tw = h.turn + blockIdx.x * TG + tgroup;  // nullptr + ... when there is one chunk: never dereferenced (y == last == 0)
   bool poisoned = false;
-  if (y > 0) {  // my turn?  (wave-uniform address: every lane reads the same value)
+  if (y > 0 && h.turn != nullptr) {  // my turn?  (wave-uniform address: every lane reads the same value)
     uint32_t spins = 0, seen;
     bool mine = true;
     while ((seen = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != y) {
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
     }
   };
   add_sum(poisoned);
-  if (y < last && !poisoned) {  // pass the turn on once the stores above have been acknowledged
+  if (y < last && !poisoned && h.turn != nullptr) {  // pass the turn on once the stores above have been acknowledged
     for (uint32_t d = 0; d < h.delay; ++d) __builtin_amdgcn_s_sleep(127);  // 0 rounds, except in the hand-off tests of the experiments build
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores are at the agent's coherence point
     __builtin_amdgcn_wave_barrier();
@@ -714,10 +716,26 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
     // -DNBODY_EXPERIMENTS builds only (tests/test_gpu_all_pairs.py: the hand-off made to wait, and made to fail)
     if (const char* e = experiment_env("NBODY_K1_TURN_SPINS")) h.spins = uint32_t(strtoul(e, nullptr, 10));
     if (const char* e = experiment_env("NBODY_K1_HANDOFF_DELAY")) h.delay = uint32_t(strtoul(e, nullptr, 10));
+    // timing experiment only (WRONG sums): no turn words — every chunk's block adds to whatever `a` holds without waiting
+    if (const char* e = experiment_env("NBODY_K1_NO_HANDOFF"); e && e[0] == '1') h.turn = nullptr;
   }
   src_rec<T, D>* packed = nullptr;
   const k1_rule* rule   = nullptr;
   if (int r = ap_prepare<T, D>(s, st, true, &packed, &rule, h.turn, h.turn ? sgpr_turn_words<R, JS>(s->count) : 0)) return r;
+#ifdef NBODY_EXPERIMENTS
+  if (const char* e = getenv("NBODY_K1_RULE_FORCE"); e && JS == 8 && D == 3) {  // timing experiment: one rule per instantiation
+    if (e[0] == '1')
+      hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS, 1>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
+                         packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                         plan.tiles_per_chunk, h, rule);
+    else
+      hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS, 2>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
+                         packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
+                         plan.tiles_per_chunk, h, rule);
+    NB_HIP(hipGetLastError());
+    return NBODY_OK;
+  }
+#endif
   hipLaunchKernelGGL((all_pairs_force_sgpr_kernel<T, D, R, JS>), dim3(blocks, plan.chunks), dim3(64 * kSgprWaves<JS>), 0, st,
                      packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
                      plan.tiles_per_chunk, h, rule);

@@ -154,7 +154,10 @@ class ShardedOctree(ShardedAllPairs):
     it from the gathered positions (bounds + insert + multipoles: 0.65 ms of a 4.5 ms step at N=1e6 on one MI355X) and
     walks it for its own bodies only; the octree does not permute bodies, so v, a, ao stay local and the one exchange per
     step is the same all-gather of positions as for all-pairs.  A body's force depends on the tree and that body alone:
-    any world size gives bitwise the single-GPU trajectory."""
+    any world size gives bitwise the single-GPU trajectory.
+
+    FROZEN (round 5): north_star scopes the multi-GPU path to all-pairs and SURVEY 8(e) says "replicas only" for the trees.  This
+    class stays because the multi-process tests use it as a second client of the exchange; it is not benchmarked and not grown."""
 
     def __init__(self, hs, rank, world, theta=0.5, **kw):
         super().__init__(hs, rank, world, **kw)

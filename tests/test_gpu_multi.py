@@ -36,7 +36,7 @@ def test_bench_self_launch_forced_dist_matches_plain_run():
     """`python bench.py --gpus 1` through the launcher (NBODY_BENCH_FORCE_DIST=1: parent -> torch.distributed.run -> rank 0,
     RCCL process group, nbody_comm, barrier, all-gather, max-reduce) reports the same workload, kernel and — within the
     box's run-to-run spread — the same rate as the plain single-process run."""
-    args = ("--gpus", "1", "--steps", "2", "--warmup", "1", "--bodies", str(1 << 17), "--no-cpu-baseline")
+    args = ("--gpus", "1", "--steps", "2", "--warmup", "1", "--bodies", str(1 << 17), "--no-cpu-baseline", "--no-other-configs")
     plain = _bench({}, *args)
     forced = _bench({"NBODY_BENCH_FORCE_DIST": "1"}, *args)
     assert plain["rccl_world"] is None and plain["n_gpus"] == 1
@@ -54,6 +54,28 @@ def test_bench_self_launch_forced_dist_matches_plain_run():
     assert plain["config"]["n_bodies"] == forced["config"]["n_bodies"] == 1 << 17
     assert abs(forced["value"] / plain["value"] - 1.0) < 0.3, (forced["value"], plain["value"])
     assert 0.2 < plain["roofline"]["frac"] < 0.7
+
+
+def test_bench_line_carries_configs_2_to_4_and_the_handoff_status():
+    """The line the driver records also times BASELINE.json configs[1..3] (after the headline's clock has stopped) with each one's
+    dominant kernel, its average launch time from HIP events, and the fraction of the roofline that bounds it; and K1's chunk
+    hand-off status over the run (no failure; how many waves had to wait)."""
+    line = _bench({}, "--gpus", "1", "--steps", "1", "--warmup", "1", "--bodies", str(1 << 16), "--no-cpu-baseline")
+    assert line["roofline"]["handoff"]["failed"] is False and line["roofline"]["handoff"]["polls"] >= 0
+    cfg = line["configs"]
+    assert len(cfg) == 3 and not any("failed" in c for c in cfg), cfg
+    c2, c3, c4 = cfg
+    assert "65536" in c2["workload"] and "all_pairs_force_sgpr_kernel<double,3" in c2["kernel"] and c2["bound"] == "valu_fp64"
+    assert 0.25 < c2["frac"] < 0.6 and c2["avg_kernel_ms"] <= c2["ms_per_step"] <= c2["avg_kernel_ms"] + 0.08, c2   # the step IS its K1 (+ 40 us)
+    assert c2["handoff"]["failed"] is False
+    assert "262144" in c3["workload"] and "collapsed" in c3["kernel"] and c3["bound"] == "valu_fp32" and 0.2 < c3["frac"] < 0.6, c3
+    assert c3["avg_kernel_ms"] <= c3["ms_per_step"] * 1.02
+    assert "1000000" in c4["workload"] and "bvh_force_sweep_isa_kernel" in c4["kernel"] and c4["bound"] == "valu_issue", c4
+    assert 2e11 < c4["node_tests_per_s"] < 2e12 and 2000 < c4["node_tests_per_body"] < 8000, c4
+    assert c4["avg_kernel_ms"] < c4["ms_per_step"] < c4["avg_kernel_ms"] + 1.0
+    assert c4["not_the_bound"]["hbm_cold_bytes_per_s"] > c4["not_the_bound"]["hbm_peak_bytes_per_s"]   # why 8(d)'s HBM model is not the bound
+    for c in cfg:
+        assert c["ms_per_step"] > 0 and c["body_steps_per_s"] > 0
 
 
 def test_bench_refuses_more_gpus_than_visible():
@@ -194,6 +216,7 @@ def test_bench_multi_rank_rehearsal_on_one_gpu():
     ("stale_exchange:1", "after the warm-up exchange"),   # a rank whose exchange delivers nothing: caught before the clock starts
     ("stale_late:1", "after the timed steps"),            # ... from the first timed step on: caught by the end-of-run checksum
     ("corrupt_a:1", "bitwise_vs_single failed"),          # a rank whose rows differ from the single-GPU sum
+    ("nan_a:1", "NaN accelerations or reports a failed K1 chunk hand-off"),   # a NaN row OUTSIDE the sampled windows (what a failed hand-off leaves)
 ])
 def test_bench_multi_rank_run_fails_on_a_broken_exchange(fault, needle):
     """a multi-rank line cannot be green with a dead exchange.  Rehearsed on the one-GPU box (two ranks on

@@ -1,8 +1,9 @@
 #!/bin/bash
 # One GPU-box session that produces everything kept under profiles/<tag>/: the bench line, its rocprofv3 summaries (stamped),
 # the per-config timings, the reference-shaped benchmark logs + scraped tables, and PMC passes of K2 and K9.
-# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r04
-TAG=${1:-r04}
+# Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r05   (add `short` as a second argument to skip the
+# reference-shaped matrix and the octree / small-tree sets: the parts round 5 did not touch)
+TAG=${1:-r05}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -11,6 +12,19 @@ echo "== bench"; timeout -k 10 300 python3 bench.py --steps 5 --warmup 1 > $O/be
 echo "== profile bench"; timeout -k 10 500 bash tools/profile_bench.sh $TAG > $O/profile_bench.txt 2>&1; tail -5 $O/profile_bench.txt
 echo "== configs"; timeout -k 10 300 python3 tools/measure_configs.py > $O/configs_all.json 2> $O/configs_all.err; grep -c config $O/configs_all.json
 echo "== K1 sizes"; timeout -k 10 200 python3 tools/time_all_pairs.py 10 > $O/k1_times.json 2> $O/k1_times.err
+echo "== round 5: stamped PMC summaries of K2 / K9, config 2's gaps and states, K1's hand-off"
+timeout -k 10 400 python3 tools/pmc_configs.py $O > $O/pmc_configs.txt 2>&1; cat $O/pmc_configs.txt
+timeout -k 10 300 bash tools/config2_gaps.sh $TAG > /dev/null 2>&1; tail -30 $O/config2_gaps.txt
+timeout -k 10 200 python3 tools/c2_state_probe.py > $O/config2_state_probe.txt 2>&1
+timeout -k 10 100 python3 tools/c2_clock_ramp.py > $O/config2_clock_ramp.txt 2>&1
+timeout -k 10 200 python3 tools/k1_handoff_report.py > $O/k1_handoff_polls.txt 2>&1; cat $O/k1_handoff_polls.txt
+timeout -k 10 300 python3 tools/k1_handoff_cost.py > $O/k1_handoff_cost.txt 2>&1; cat $O/k1_handoff_cost.txt
+timeout -k 10 300 python3 tools/k1_rule_instances.py > $O/k1_rule_instances.txt 2>&1; cat $O/k1_rule_instances.txt
+if [ -f stdpar-nbody_amd/libnbody_hip_var_r3.so ] && [ -f stdpar-nbody_amd/libnbody_hip_var_r4head.so ]; then
+  AB_CASES="f32:uniform:262144,f32:galaxy:262144,f32:uniform:100000,f64:uniform:65536,f64:galaxy:262144,f64:galaxy:1048576" timeout -k 10 600 python3 tools/ab_all_pairs.py libnbody_hip_var_r3.so libnbody_hip_var_r4head.so libnbody_hip.so > $O/ab_k1_r3_r4_r5.txt 2>&1; cat $O/ab_k1_r3_r4_r5.txt
+fi
+STEP_GRAPH_N=64,257,513,1000,1024,2048 timeout -k 10 200 python3 tools/time_step_graph.py > $O/step_graph_small.txt 2>&1; STEP_GRAPH_N=64,257,513,1000,1024,2048 timeout -k 10 200 python3 tools/time_step_graph.py float >> $O/step_graph_small.txt 2>&1
+if [ "$2" = "short" ]; then exit 0; fi
 echo "== matrix"; timeout -k 10 400 bash tools/benchmark.sh 200 > $O/benchmark.log 2> $O/benchmark.err; python3 tools/scrape_bench_log.py $O/benchmark.log > $O/benchmark.csv; cat $O/benchmark.csv
 echo "== detailed"; timeout -k 10 400 bash tools/benchmark_detailed.sh 1000 100000 > $O/benchmark_detailed.log 2> $O/benchmark_detailed.err; python3 tools/scrape_bench_log.py $O/benchmark_detailed.log > $O/benchmark_detailed.csv; cat $O/benchmark_detailed.csv
 echo "== PMC K2 / K9"

@@ -247,35 +247,49 @@ __global__ __launch_bounds__(kBlock) void k1_prepare_kernel(const T* __restrict_
       __hip_atomic_store(partial + size_t(blockIdx.x) * (2 * D) + threadIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  // the ticket: the block that draws the last number knows that every other block's stores are out
-  __threadfence();
+  // The ticket: the block that draws the last number knows that every other block's partial sums are out.  No __threadfence():
+  // an agent-scope fence writes back and invalidates the XCD's whole L2 — which holds the records this kernel has just packed —
+  // and 4096 of them made this launch 430 us at N = 2^20.  The partial sums are agent-scope stores (written through), the wave that
+  // issued them waits for their acknowledgement (s_waitcnt 0) before its lane 0 draws the ticket, and the last block reads them
+  // with agent-scope loads; everything else this kernel writes is read by the NEXT kernel only.
+  __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
-  if (threadIdx.x == 0) last_s = atomicAdd(&rule->ticket, 1u) == gridDim.x - 1u;
+  if (threadIdx.x == 0) last_s = __hip_atomic_fetch_add(&rule->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
   __syncthreads();
   if (!last_s) return;
-  __threadfence();
   if constexpr (MOMENTS) {
-    double acc = 0.0;  // thread t: moment t % (2 D) of the blocks t / (2 D), t / (2 D) + G, ... in ascending order (G groups)
-    constexpr int G = kBlock / (2 * D);
+    // thread t: moment q = t % (2 D) of the blocks g, g + G, g + 2 G, ... in ascending order (g = t / (2 D), G groups); eight
+    // loads in flight at a time (one after the other this loop was 50 us of latency at N = 262 144), added in index order
+    double acc = 0.0;
+    constexpr int G = kBlock / (2 * D), U = 8;
     const int q = threadIdx.x % (2 * D), g = threadIdx.x / (2 * D);
-    if (g < G)
-#pragma unroll 1
-      for (uint32_t b = uint32_t(g); b < gridDim.x; b += G)
-        acc += __hip_atomic_load(partial + size_t(b) * (2 * D) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g < G) {
+      for (uint32_t b0 = uint32_t(g); b0 < gridDim.x; b0 += G * U) {
+        double v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t b = b0 + uint32_t(u) * G;
+          v[u] = b < gridDim.x ? __hip_atomic_load(partial + size_t(b) * (2 * D) + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += v[u];  // (+ 0.0 past the end: no change)
+      }
+    }
     __shared__ double fin[kBlock];
     fin[threadIdx.x] = g < G ? acc : 0.0;
     __syncthreads();
+    if (threadIdx.x < 2 * D) {  // thread q: the G group sums of moment q in index order
+      double tot = 0.0;
+#pragma unroll 6
+      for (int gg = 0; gg < G; ++gg) tot += fin[gg * (2 * D) + threadIdx.x];
+      fin[threadIdx.x] = tot;   // (row 0 of fin: its values have been read by exactly this thread)
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
       double vol = 1.0;
-#pragma unroll 1
+#pragma unroll
       for (int k = 0; k < D; ++k) {
-        double m1 = 0.0, m2 = 0.0;
-#pragma unroll 1
-        for (int gg = 0; gg < G; ++gg) {  // groups in index order (not unrolled: 2 D x 42 loads in flight took 260 VGPRs)
-          m1 += fin[gg * (2 * D) + k];
-          m2 += fin[gg * (2 * D) + D + k];
-        }
-        const double mean = m1 / double(sz), var = m2 / double(sz) - mean * mean;
+        const double mean = fin[k] / double(sz), var = fin[D + k] / double(sz) - mean * mean;
         vol *= var > 0.0 ? __builtin_sqrt(12.0 * var) : 0.0;
       }
       rule->volume = vol;

@@ -333,7 +333,9 @@ struct k1_status {  // one per (device, stream), device memory, zeroed when allo
   unsigned long long polls, waits;
 };
 struct k1_handoff {
+  void* sums;         // small launches (k1_collect): every chunk's sum of every target, [chunk][target block][group][r][k][lane]; else nullptr
   uint32_t* turn;     // one word per (target block, target group): the chunk whose sum is added next, or kTurnPoison
+                      // (k1_collect: the number of chunks that have delivered their sums)
   k1_status* status;
   uint32_t spins;     // polls before a waiting wave gives up (kTurnSpins; lowered only by the experiments build's tests)
   uint32_t delay;     // s_sleep(127) rounds before a turn is passed on (0; the experiments build's tests make successors wait)
@@ -424,6 +426,43 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   if (jpart != 0) return;
   const uint32_t y = blockIdx.y, last = gridDim.y - 1u;
   uint32_t* const tw = h.turn + blockIdx.x * TG + tgroup;  // nullptr + ... when there is one chunk: never dereferenced (y == last == 0)
+  if (h.sums != nullptr) {
+    // Small launches (all blocks resident within a few rounds: the blocks of one target group's sixteen chunks finish TOGETHER, and
+    // a chain of turns is fifteen dependent round trips through memory — 18 of 41 us at N = 4096, 42 of 76 us in float at 8192):
+    // every chunk's wave stores its sum, then draws a ticket; whoever draws the last one — whichever chunk it is — adds the
+    // sums IN CHUNK ORDER, ((s_0 + s_1) + s_2) + ..., applies c and writes `a`: the same bits as the turns give, no waiting, no
+    // failure mode.  The sums are agent-scope stores acknowledged (s_waitcnt 0) before the ticket is drawn.
+    const size_t group_scalars = size_t(R) * D * 64;
+    T* const all  = static_cast<T*>(h.sums);
+    T* const mine = all + ((size_t(y) * gridDim.x + blockIdx.x) * TG + tgroup) * group_scalars;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int k = 0; k < D; ++k) __hip_atomic_store(mine + (r * D + k) * 64 + lane, acc[r][k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t drawn = 0;
+    if (lane == 0) drawn = __hip_atomic_fetch_add(tw, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (uint32_t(__builtin_amdgcn_readfirstlane(int(drawn))) != last) return;
+    T tot[R][D];
+    for (uint32_t yy = 0; yy <= last; ++yy) {
+      const T* src = all + ((size_t(yy) * gridDim.x + blockIdx.x) * TG + tgroup) * group_scalars;
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+          const T v = __hip_atomic_load(src + (r * D + k) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tot[r][k] = yy == 0 ? v : tot[r][k] + v;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (ti[r] < count) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) a[uint64_t(ti[r]) * D + k] = c * tot[r][k];
+      }
+    return;
+  }
   bool poisoned = false;
   if (y > 0 && h.turn != nullptr) {  // my turn?  (wave-uniform address: every lane reads the same value)
     uint32_t spins = 0, seen;
@@ -525,7 +564,7 @@ struct scratch_buf {
 struct packed_slot {
   int device;
   hipStream_t stream;
-  scratch_buf buf[5];  // 0: packed sources, 1: K1 turn words, 2: energies work area, 3: bounding-box keys, 4: K1 hand-off status (k1_status)
+  scratch_buf buf[6];  // 0: packed sources, 1: K1 turn words, 2: energies work area, 3: the pair rule + partial moments, 4: K1 hand-off status (k1_status), 5: K1 chunk sums of small launches
   std::vector<void*> retired;
 };
 std::mutex g_packed_mu;
@@ -708,6 +747,18 @@ static int ap_prepare(const nbody_state* s, hipStream_t st, bool pack, src_rec<T
   return NBODY_OK;
 }
 
+// How the chunks' sums of a launch meet (bitwise the same either way): collected by the last chunk to arrive when the whole grid is
+// resident within two rounds (<= 2048 blocks: up to 3 MB of sums), passed from chunk to chunk in `a` otherwise (no scratch).
+// Measured (profiles/r05/k1_handoff_cost.txt; f64, us per launch, collected / turns / no protocol at all): N = 2048 16.2 / 23.5 / 15.1,
+// 4096 23 / 41 / 20, 8192 55 / 70 / 51, f32 8192 34 / 76 / 29 — and at 4096 blocks (N = 16 384) 176 / 172 / 172: turns from there on.
+constexpr uint32_t kCollectMaxBlocks = 2048;
+static bool k1_collect(uint32_t target_blocks, uint32_t chunks) { return chunks > 1 && uint64_t(target_blocks) * chunks <= kCollectMaxBlocks; }
+template <typename T, int D, int R, int JS>
+static size_t k1_collect_bytes(uint32_t target_blocks, uint32_t chunks) {
+  constexpr int TG = kSgprWaves<JS> / JS;
+  return sizeof(T) * size_t(chunks) * target_blocks * TG * R * D * 64;
+}
+
 // words of the turn array for a launch of `blocks` target blocks (one per target group of a block)
 template <int R, int JS>
 static size_t sgpr_turn_words(uint32_t count) {
@@ -720,18 +771,23 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  k1_handoff h{nullptr, nullptr, kTurnSpins, 0u};
+  k1_handoff h{nullptr, nullptr, nullptr, kTurnSpins, 0u};
   if (plan.chunks > 1) {  // before anything is queued: a failed reservation leaves the stream untouched
     void* q = nullptr;
     if (int r = ap_scratch_get(st, 1, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), &q)) return r;
     h.turn = static_cast<uint32_t*>(q);
+    if (k1_collect(blocks, plan.chunks)) {
+      if (int r = ap_scratch_get(st, 5, k1_collect_bytes<T, D, R, JS>(blocks, plan.chunks), &q)) return r;
+      h.sums = q;
+    }
     if (int r = ap_scratch_get(st, 4, sizeof(k1_status), &q)) return r;
     h.status = static_cast<k1_status*>(q);
     // -DNBODY_EXPERIMENTS builds only (tests/test_gpu_all_pairs.py: the hand-off made to wait, and made to fail)
     if (const char* e = experiment_env("NBODY_K1_TURN_SPINS")) h.spins = uint32_t(strtoul(e, nullptr, 10));
     if (const char* e = experiment_env("NBODY_K1_HANDOFF_DELAY")) h.delay = uint32_t(strtoul(e, nullptr, 10));
     // timing experiment only (WRONG sums): no turn words — every chunk's block adds to whatever `a` holds without waiting
-    if (const char* e = experiment_env("NBODY_K1_NO_HANDOFF"); e && e[0] == '1') h.turn = nullptr;
+    if (const char* e = experiment_env("NBODY_K1_NO_HANDOFF"); e && e[0] == '1') h.turn = nullptr, h.sums = nullptr;
+    if (const char* e = experiment_env("NBODY_K1_COLLECT"); e && e[0] == '0') h.sums = nullptr;  // experiments: turns at every size
   }
   src_rec<T, D>* packed = nullptr;
   const k1_rule* rule   = nullptr;
@@ -815,9 +871,15 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
   const char* t = sizeof(T) == 8 ? "double" : "float";
   const char* pair = sizeof(T) == 4 ? (s->sz >= kFarMinBodies ? "rsq+rcp[m y^3 at r2 >= 4 if sparse]" : "rsq+rcp")
                                     : s->sz >= kFarMinBodies ? "far3[-eps if sparse]/near3" : "far3/near3";
-  if (p.scalar)
+  if (p.scalar) {
+    bool collect = false;
+    with_k1_instance(p, [&](auto r, auto js) {
+      constexpr int TB = (kSgprWaves<decltype(js)::value> / decltype(js)::value) * 64 * decltype(r)::value;
+      collect = k1_collect((s->count + TB - 1) / TB, p.chunks);
+    });
     snprintf(out, len, "all_pairs_force_sgpr_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=%u%s pair=%s", t, D, p.r, p.js, kTileJ, p.chunks,
-             p.chunks > 1 ? "(summed in turn into a)" : "", pair);
+             p.chunks > 1 ? (collect ? "(summed in chunk order by the last to arrive)" : "(summed in turn into a)") : "", pair);
+  }
   else
     snprintf(out, len, "all_pairs_force_kernel<%s,%d,R=%d,JS=%d> tile=%d chunks=1 pair=%s", t, D, p.r, p.js, kTileJ, pair);
   return NBODY_OK;
@@ -841,6 +903,14 @@ int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
     with_k1_instance(p, [&](auto r, auto js) { words = sgpr_turn_words<decltype(r)::value, decltype(js)::value>(s->count); });
     if (!words) return int(NBODY_OK);
     if (int rc = ap_scratch_get(st, 1, sizeof(uint32_t) * words, &q)) return rc;
+    size_t sums = 0;
+    with_k1_instance(p, [&](auto r, auto js) {
+      constexpr int RR = decltype(r)::value, JJ = decltype(js)::value;
+      const uint32_t blocks = (s->count + (kSgprWaves<JJ> / JJ) * 64 * RR - 1) / ((kSgprWaves<JJ> / JJ) * 64 * RR);
+      if (k1_collect(blocks, p.chunks)) sums = k1_collect_bytes<T, decltype(tg)::dim, RR, JJ>(blocks, p.chunks);
+    });
+    if (sums)
+      if (int rc = ap_scratch_get(st, 5, sums, &q)) return rc;
     return ap_scratch_get(st, 4, sizeof(k1_status), &q);
   });
 }

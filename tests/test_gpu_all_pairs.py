@@ -692,12 +692,14 @@ def test_config2_as_written_100_steps(nb, oracle):
 
 
 def test_k1_handoff_status_of_ordinary_runs(nb):
-    """K1's chunks add their sums into `a` in turn (all_pairs.hip, all_pairs_force_sgpr_kernel).  The stream's status block must say
+    """K1's chunks add their sums into `a` in turn (all_pairs.hip, all_pairs_force_sgpr_kernel; launches of up to 2048 blocks collect
+    them instead: same bits, no waiting).  The stream's status block must say
     after ordinary launches — whole systems and rank windows, both precisions — that no hand-off failed; how many waves had to
     poll for their turn is reported, not asserted (normally none: the predecessor finished a round of blocks earlier)."""
     for dtype, n, first, count in ((1, 8192, 0, None), (0, 8192, 0, None), (1, 70001, 0, None), (1, 1 << 18, 1 << 17, 1 << 15)):
         dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
-        assert "summed in turn" in nb.describe_all_pairs(dev.state(first, count))
+        desc = nb.describe_all_pairs(dev.state(first, count))
+        assert ("by the last to arrive" if n == 8192 else "summed in turn") in desc, desc
         for _ in range(3):
             dev.all_pairs_force(first, count)
         dev.sync()                                   # would raise NBODY_ERR_STATE
@@ -735,8 +737,10 @@ def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
         nb = load_package()
         nb.LIB_PATH = {lib!r}
         dtype = {dtype}
-        def force(n, first=0, count=None, tpt=0, delay=None, spins=None, expect_failure=False):
-            for k, v in (("NBODY_K1_HANDOFF_DELAY", delay), ("NBODY_K1_TURN_SPINS", spins)):
+        def force(n, first=0, count=None, tpt=0, delay=None, spins=None, expect_failure=False, collect=None):
+            # launches of up to 2048 blocks collect their chunks' sums instead of passing turns (no waiting there at all): the
+            # hand-off is tested with NBODY_K1_COLLECT=0, which makes every size pass turns
+            for k, v in (("NBODY_K1_HANDOFF_DELAY", delay), ("NBODY_K1_TURN_SPINS", spins), ("NBODY_K1_COLLECT", collect)):
                 os.environ.pop(k, None)
                 if v is not None:
                     os.environ[k] = str(v)
@@ -751,17 +755,19 @@ def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
                 dev.close()
                 return a, st
             return dev
-        for n, first, count, tpt in ((8192, 0, None, 0), (8192, 0, None, 2), (50000, 20000, 9000, 0), (3000, 0, None, 0)):
-            a0, st0 = force(n, first, count, tpt)
-            a1, st1 = force(n, first, count, tpt, delay=50)
-            assert not st0["failed"] and not st1["failed"], (st0, st1)
+        for n, first, count, tpt in ((8192, 0, None, 0), (8192, 0, None, 2), (50000, 20000, 9000, 0), (3000, 0, None, 0), (21000, 0, None, 0)):
+            a0, st0 = force(n, first, count, tpt, collect=0)
+            a1, st1 = force(n, first, count, tpt, delay=50, collect=0)
+            a2, st2 = force(n, first, count, tpt)            # as shipped: the small ones collect, the large one passes turns
+            assert not st0["failed"] and not st1["failed"] and not st2["failed"], (st0, st1, st2)
             assert st1["polls"] > 0 and st1["waits"] > 0, ("nobody waited", n, st1)
             assert np.array_equal(a0, a1), ("delayed hand-off changed a", n, first, count, tpt)
+            assert np.array_equal(a0, a2), ("collected sums differ from sums passed in turn", n, first, count, tpt)
             print("waited", n, first, count, tpt, st1["waits"], st1["polls"])
         # the turn that never comes in time
         n = 8192
         a0, _ = force(n)
-        dev = force(n, delay=3000, spins=3, expect_failure=True)
+        dev = force(n, delay=3000, spins=3, expect_failure=True, collect=0)
         try:
             dev.sync()
             raise SystemExit("nbody_stream_sync returned success after a failed hand-off")
@@ -781,7 +787,7 @@ def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
         assert np.isnan(hs.a[bad]).all(), "a row is partly NaN"
         print("failed as it should:", int(bad.sum()), "of", n, "rows NaN;", st)
         # sticky, then cleared; the context works again
-        os.environ.pop("NBODY_K1_HANDOFF_DELAY"); os.environ.pop("NBODY_K1_TURN_SPINS")
+        os.environ.pop("NBODY_K1_HANDOFF_DELAY"); os.environ.pop("NBODY_K1_TURN_SPINS"); os.environ.pop("NBODY_K1_COLLECT")
         try:
             dev.sync()
             raise SystemExit("the failure flag is not sticky")

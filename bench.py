@@ -291,7 +291,9 @@ def other_configs(nb, torch):
     out.append({"workload": "bvh 3D double, -n 1000000 -s 20 --workload galaxy --theta 0.5, 1 GPU: steps 11-20 of the recorded step",
                 "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3),
                 "kernel": "bvh_force_sweep_isa_kernel<double,3> (+ bvh_items_kernel; K4-K8 and K3 are the rest of the step)",
-                "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_bvh_compute_force in steps 21-30 of the evolving system",
+                "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_bvh_compute_force in steps 21-30 of the evolving system (the work-item "
+                                                                "kernel 36 us + the sweep; + a 22-us threshold rewrite, which an eager traversal of a tree "
+                                                                "that has been recorded always makes)",
                 "bound": "valu_issue", "node_tests_per_s": node_tests / (k_ms * 1e-3), "node_tests_per_body": node_tests / n,
                 "force_terms_per_body": terms / n,
                 "frac": ev["valu_issue_frac"] if ev else None,

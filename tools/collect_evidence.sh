@@ -17,6 +17,7 @@ timeout -k 10 400 python3 tools/pmc_configs.py $O > $O/pmc_configs.txt 2>&1; cat
 timeout -k 10 300 bash tools/config2_gaps.sh $TAG > /dev/null 2>&1; tail -30 $O/config2_gaps.txt
 timeout -k 10 200 python3 tools/c2_state_probe.py > $O/config2_state_probe.txt 2>&1
 timeout -k 10 100 python3 tools/c2_clock_ramp.py > $O/config2_clock_ramp.txt 2>&1
+timeout -k 10 100 bash tools/prepare_kernel_time.sh > $O/prepare_kernel_time.txt 2>&1
 timeout -k 10 200 python3 tools/k1_handoff_report.py > $O/k1_handoff_polls.txt 2>&1; cat $O/k1_handoff_polls.txt
 timeout -k 10 300 python3 tools/k1_handoff_cost.py > $O/k1_handoff_cost.txt 2>&1; cat $O/k1_handoff_cost.txt
 timeout -k 10 300 python3 tools/k1_rule_instances.py > $O/k1_rule_instances.txt 2>&1; cat $O/k1_rule_instances.txt

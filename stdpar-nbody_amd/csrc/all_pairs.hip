@@ -566,6 +566,8 @@ struct packed_slot {
   hipStream_t stream;
   scratch_buf buf[6];  // 0: packed sources, 1: K1 turn words, 2: energies work area, 3: the pair rule + partial moments, 4: K1 hand-off status (k1_status), 5: K1 chunk sums of small launches
   std::vector<void*> retired;
+  bool k1_dirty  = false;  // a K1 that passes turns (or a recorded step, which may hold one) has been queued since the status was last read
+  bool k1_failed = false;  // the last read found the sticky error set
 };
 std::mutex g_packed_mu;
 std::vector<packed_slot> g_packed_slots;
@@ -810,6 +812,7 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
                      packed, static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), s->sz, s->first, s->count,
                      plan.tiles_per_chunk, h, rule);
   NB_HIP(hipGetLastError());
+  if (h.turn != nullptr && h.sums == nullptr) ap_status_mark(st);  // turns were passed: the next wait for this stream reads the status
   return NBODY_OK;
 }
 
@@ -917,13 +920,22 @@ int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
 
 // The hand-off status of a stream's K1 launches (see all_pairs_force_sgpr_kernel).  Waits for the stream.  out (may be NULL):
 // {err, block, group, chunk, polls, waits}.  Returns NBODY_ERR_STATE (and the message) while the sticky error word is set.
+void ap_status_mark(hipStream_t st) {
+  const int dev = stream_device(st);
+  std::lock_guard<std::mutex> lock(g_packed_mu);
+  for (auto& sl : g_packed_slots)
+    if (sl.stream == st && sl.device == dev) sl.k1_dirty = true;
+}
+
 int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear) {
   const int dev = stream_device(st);
   k1_status* dptr = nullptr;
   {
+    // the 32-byte copy is made only when it can say something new: an explicit query, a turn-passing K1 or a recorded step queued
+    // since the last read, or an error already seen (a tree run in --csv-detailed mode waits for the stream six times per step)
     std::lock_guard<std::mutex> lock(g_packed_mu);
     for (auto& sl : g_packed_slots)
-      if (sl.stream == st && sl.device == dev) dptr = static_cast<k1_status*>(sl.buf[4].ptr);
+      if (sl.stream == st && sl.device == dev && (out != nullptr || sl.k1_dirty || sl.k1_failed)) dptr = static_cast<k1_status*>(sl.buf[4].ptr);
   }
   k1_status h{};
   if (dptr) NB_HIP(hipMemcpyAsync(&h, dptr, sizeof h, hipMemcpyDeviceToHost, st));
@@ -935,6 +947,11 @@ int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear) {
   if (out) {
     out[0] = h.err, out[1] = h.block, out[2] = h.group, out[3] = h.chunk;
     out[4] = h.polls, out[5] = h.waits;
+  }
+  if (dptr) {
+    std::lock_guard<std::mutex> lock(g_packed_mu);
+    for (auto& sl : g_packed_slots)
+      if (sl.stream == st && sl.device == dev) sl.k1_dirty = false, sl.k1_failed = h.err != 0 && !clear;
   }
   if (h.err) {
     set_error("all-pairs: the chunk hand-off of target block %u (group %u) failed at source chunk %u: the block of chunk %u never passed "

@@ -516,6 +516,7 @@ inline int check_tuning(int split, int tpt, int path) {
 int ap_scratch_reserve(hipStream_t st, const nbody_state* view);
 void ap_scratch_release(hipStream_t st);
 int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out);  // which: 0 packed sources, 1 K1 turn words, 2 energies, 3 the pair rule (k1_rule + the blocks' partial moments), 4 K1 hand-off status, 5 K1 chunk sums of small launches
+void ap_status_mark(hipStream_t st);  // a recorded step is being replayed on st: it may hold a turn-passing K1
 int ap_status_read(hipStream_t st, unsigned long long out[6], bool clear);  // waits for the stream; NBODY_ERR_STATE while a K1 hand-off failure is recorded
 int ap_pack_sources(const nbody_state* s, hipStream_t st, void** packed_out);
 void ap_auto_chunks(uint32_t sz, uint32_t* chunks, uint32_t* tiles_per_chunk);

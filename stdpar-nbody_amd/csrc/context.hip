@@ -224,6 +224,7 @@ extern "C" int nbody_graph_launch(nbody_graph* g, void* stream) {
   NB_ARG(g != nullptr && g->exec != nullptr, "graph is NULL");
   device_guard guard(stream_device(as_stream(stream)));
   NB_HIP(hipGraphLaunch(g->exec, as_stream(stream)));
+  ap_status_mark(as_stream(stream));
   return NBODY_OK;
 }
 

@@ -66,7 +66,7 @@ def test_bench_line_carries_configs_2_to_4_and_the_handoff_status():
     assert len(cfg) == 3 and not any("failed" in c for c in cfg), cfg
     c2, c3, c4 = cfg
     assert "65536" in c2["workload"] and "all_pairs_force_sgpr_kernel<double,3" in c2["kernel"] and c2["bound"] == "valu_fp64"
-    assert 0.25 < c2["frac"] < 0.6 and c2["avg_kernel_ms"] <= c2["ms_per_step"] <= c2["avg_kernel_ms"] + 0.08, c2   # the step IS its K1 (+ 40 us)
+    assert 0.25 < c2["frac"] < 0.6 and 0.97 * c2["avg_kernel_ms"] <= c2["ms_per_step"] <= c2["avg_kernel_ms"] + 0.08, c2   # the step IS its K1 (+ 40 us; the two are timed over different steps)
     assert c2["handoff"]["failed"] is False
     assert "262144" in c3["workload"] and "collapsed" in c3["kernel"] and c3["bound"] == "valu_fp32" and 0.2 < c3["frac"] < 0.6, c3
     assert c3["avg_kernel_ms"] <= c3["ms_per_step"] * 1.02

@@ -6,21 +6,23 @@
 //   * sources are packed (x, m) records visited in tiles of 512; every tile is cut into JS slices, one per wave of the
 //     block that shares a target group, and the tile sequence into source chunks over grid.y — both from sz alone, so a
 //     shard window (N/8 targets on one GPU) sums exactly as the whole system does and still fills the chip;
-//   * slice partials are combined through LDS in wave order, chunk sums added in chunk order into `a` by the chunks' blocks in turn:
-//     deterministic, and independent of how bodies are sharded over GPUs.
+//   * slice partials are combined through LDS in wave order, chunk sums added in chunk order — c * (((s_0 + s_1) + s_2) + ...) — by
+//     the chunks' blocks themselves: passed from block to block in `a` (a turn word per target group; a failure is loud: k1_status), or,
+//     where the whole grid is resident at once (<= 2048 blocks), collected by whichever chunk arrives last.  Deterministic, the same
+//     bits either way, and independent of how bodies are sharded over GPUs.
 //   Two ways of bringing a source record to the 64 lanes that all need the same one (bitwise the same result):
 //   - LDS tiles (all_pairs_force_kernel): tiles staged in LDS by all 256 lanes with a register prefetch of the
 //     next tile; the inner loop reads each record as an LDS broadcast (ds_read_b128) into VGPRs;
 //   - scalar stream (all_pairs_force_sgpr_kernel, default from 2048 bodies): the record is wave-uniform, so it belongs in
-//     SGPRs: a pre-pass packs the records once per call (32 B x N), every wave streams its slice with
-//     s_load_dwordx16 two batches deep (inline asm) and the VALU instructions take their source operands from SGPRs.
-//     No staging loads, no LDS traffic, no barriers in the loop, half the VGPRs.
+//     SGPRs: ONE pre-pass launch per call (k1_prepare_kernel) packs the records (32 B x N), sums the positions' moments for the
+//     pair rule and resets the turn words; every wave streams its slice with s_load_dwordx16 two batches deep (inline asm) and the
+//     VALU instructions take their source operands from SGPRs.  No staging loads, no LDS traffic, no barriers in the loop, half
+//     the VGPRs.
 //   Pair rule (common.hpp, pair_batch): f64 is reciprocal-free — 16 full-rate ops + v_rsq_f64 per pair on sparse systems
-//   (the launch-level far mode: the system's bounding box, reduced by extent_kernel before every call, says that few
-//   batches can hold a pair closer than 2), 17 + 1 on dense ones; pairs below 2^-16 take the guarded reciprocal form.
-//   Measured on one box, A/B against round 2's library (profiles/r03/ab_k1_far_mode.txt): N = 2^20 galaxy 629 -> 608 ms
-//   per pass = 36.2 TFLOP/s = 46.0 % of the 78.6 TF FP64 vector peak (round 2: 44.4 % on that box); dense (uniform) systems
-//   keep round 2's rule and time.
+//   (the launch-level far mode: the positions' variances, common.hpp k1_rule, say that few batches can hold a pair closer than 2),
+//   17 + 1 on dense ones; pairs below 2^-16 take the guarded reciprocal form.
+//   Measured: N = 2^20 galaxy 602-633 ms per pass by the clock the box sustains = 44-46.5 % of the 78.6 TF FP64 vector peak
+//   (profiles/r05/bench_n1.json; VALU 98 % busy: 97 % of what 16 + rsq allow).
 //
 // K2 (replaces src/all_pairs.h:29-50, intended semantics).  Lanes run along the SOURCE axis (one
 // ordered pair per lane and step), each wave owns 64 targets whose positions it broadcasts with
@@ -1196,7 +1198,11 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   // Measured at config 3 (f32, N = 262 144) and on the reference's matrix size (f64, N = 10^5), gpurun_out/r02/k2_times*.txt:
   // every variant with ONE pair chain per lane in flight runs at 24.05 ms (36.3 % of the FP32 vector peak) whatever NT, KS
   // and the occupancy (3 to 6 waves per SIMD); every variant that interleaves 2 or 4 chains runs at 28.7 ms — the interleaved
-  // order puts v_rsq_f32 and v_rcp_f32 back to back.  f64 (N = 10^5, ms): with the guarded rsq+rcp weight everywhere (8, 4, 4) was
+  // order puts v_rsq_f32 and v_rcp_f32 back to back.  Round 5, same box, cfg (16, 8, 1) 23.87 ms: the next tile's records prefetched
+  // into registers while this one is consumed 23.85 (the staging is not what stalls); the target's eight chains software-pipelined with
+  // sched_group_barrier (6 VALU, 1 transcendental, ...; one scheduling region per target: over the whole block of 128 pairs hipcc did
+  // not finish in 30 minutes) 27.8 — independent chains side by side are SLOWER than one chain with its two wait states, again.
+  // f64 (N = 10^5, ms): with the guarded rsq+rcp weight everywhere (8, 4, 4) was
   // the fastest at 7.47; with the reciprocal-free weight and a guarded second pass only for the blocks that held a near pair
   // (see the kernel) (8, 8, 1) 6.79, (8, 4, 1) 6.95, (8, 4, 2) 7.00, (8, 2, 2) 7.01, (8, 2, 1) 7.26, (16, 8, 1) 8.03, (8, 4, 4) 9.96.
   int cfg = sizeof(T) == 4 ? 0 : 5;

@@ -327,8 +327,8 @@ struct pair_consts<double> {
 // K1's unit of work: U source records against the R targets of a lane.  acc[r] += w * (x_j - x_i) in source order.
 // `ffar` is a property of the LAUNCH, compiled as two copies of the kernels' source loops — inside ONE loop hipcc hoists the
 // common head of the two rules above the branch and interleaves the f32 pair chains, which costs 15 % (24.4 against 21.2 ms at
-// config 3) — (ap_far_mode: the whole system's bounding box says that few batches can hold a pair closer
-// than 2; every rank and every shard window of one system computes the same value) and selects the per-pair rule:
+// config 3) — (ap_far_mode: the variances of ALL positions say that few batches can hold a pair closer than 2 — k1_rule below;
+// every rank and every shard window of one system computes the same bits) and selects the per-pair rule:
 //   dense (ffar false): f64 weight_far<true> for r2 >= 2^-16, weight<3>() below; f32 weight().
 //   sparse (ffar true): f64 weight_far<false> for r2 >= 4, weight_far<true> in [2^-16, 4), weight<3>() below;
 //                       f32 m y^3 for r2 >= 4, weight() below.

@@ -95,7 +95,9 @@ int nbody_all_pairs_force(const nbody_state* s, void* stream);
 
 /* K1's in-kernel chunk hand-off, and how it fails.  From 2048 bodies on, the source range is cut into >= 16 chunks over grid.y;
  * the block of chunk y adds its sum into `a` after the block of chunk y - 1 has (a turn word per group of targets), which fixes
- * the rounding order without a scratch array or a second launch.  A block waits only for blocks of smaller linear index.  That
+ * the rounding order without a scratch array or a second launch.  (Launches whose whole grid is resident at once — up to 2048
+ * blocks, i.e. up to 8192 targets — collect the chunks' sums instead: whichever chunk arrives last adds them in chunk order; the same
+ * bits, no waiting, nothing that can fail.)  A block waits only for blocks of smaller linear index.  That
  * this terminates rests on an ASSUMPTION about the dispatcher (true of every GPU this library targets, stated nowhere in the
  * ISA): the workgroups of a grid are started in linear index order, so the oldest unfinished block never waits.  The reference's
  * loop (src/all_pairs.h:14-27) cannot return garbage silently, and neither does this: a wave that has waited for its turn past

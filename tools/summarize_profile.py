@@ -54,6 +54,20 @@ def main():
     stats = glob.glob(os.path.join(src, "trace", "*", "*kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(dst, "bench_n1_kernel_stats.csv"))
+    # The same trace by launch SHAPE: since round 5 the command also runs configs 2-4, and config 2's K1 is the same instantiation
+    # as the headline's (another grid) — rocprofv3's per-name statistics average the two together.
+    trace = glob.glob(os.path.join(src, "trace", "*", "*kernel_trace.csv"))
+    if trace:
+        import collections
+        rows = collections.OrderedDict()
+        for r in csv.DictReader(open(trace[0])):
+            key = (r["Kernel_Name"], "x".join(r["Grid_Size_" + a] for a in "XYZ"), "x".join(r["Workgroup_Size_" + a] for a in "XYZ"))
+            rows.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+        with open(os.path.join(dst, "bench_n1_kernel_stats_by_grid.csv"), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Grid", "Workgroup", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs"])
+            for (name, grid, wg), d in sorted(rows.items(), key=lambda kv: -sum(kv[1])):
+                w.writerow([name, grid, wg, len(d), sum(d), "%.1f" % (sum(d) / len(d)), min(d), max(d)])
     line = None
     try:
         line = json.loads([l for l in open(os.path.join(src, "trace_bench.json")) if l.startswith("{")][-1])

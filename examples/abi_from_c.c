@@ -42,7 +42,9 @@ int main(void) {
   void* stream = nbody_ctx_stream(ctx);
 
   CHECK(nbody_all_pairs_force(&st, stream));
-  CHECK(nbody_download(ctx, NULL, NULL, NULL, a, NULL));
+  CHECK(nbody_download(ctx, NULL, NULL, NULL, a, NULL)); /* NBODY_ERR_STATE here if K1's chunk hand-off had failed (ABI 2.3) */
+  uint64_t k1[6];
+  CHECK(nbody_all_pairs_status(stream, k1, 0)); /* {failed, block, group, chunk, polls, waves that waited} of this stream's K1 launches */
 
   nbody_octree* tree = NULL;
   CHECK(nbody_octree_create(&tree, NBODY_F64, 3, n));
@@ -66,6 +68,7 @@ int main(void) {
   }
   printf("all-pairs max|a| %.12e\noctree    max|a| %.12e\nrelative difference %.3e\ntree size %u root mass %.6f\n", amax, a2max,
          dmax / amax, tree_size, root_mass);
+  printf("K1 hand-off: failed %llu, waves that waited %llu\n", (unsigned long long)k1[0], (unsigned long long)k1[5]);
   nbody_octree_destroy(tree);
   nbody_destroy(ctx);
   free(m); free(x); free(v); free(a); free(ao); free(a2);

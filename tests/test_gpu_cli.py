@@ -207,6 +207,7 @@ def test_abi_from_plain_c(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tree size" in r.stdout and "root mass" in r.stdout
+    assert "K1 hand-off: failed 0" in r.stdout, r.stdout   # nbody_all_pairs_status from C
 
 
 def cli_env(dim, args, env_extra, cwd=None):

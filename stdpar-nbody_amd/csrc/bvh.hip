@@ -767,7 +767,7 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
 //     `w2 < fl(theta^2 d2)` <=> `v < d2` bit for bit.  Bodies carry v = -1 (always accepted); a NaN distance accepts, as
 //     before, so no walk can descend below the body level whatever the state holds.  The per-lane form keeps the reference's
 //     product; the tests hold the two forms equal decision by decision;
-//   * two record blocks (s[48:63], s[64:79]) and two sets of position registers used in turn by two copies of the step: the
+//   * two record blocks (s[40:55], s[56:71]) and two sets of position registers used in turn by two copies of the step: the
 //     next record is requested into the other block as soon as the decision is made and the accepted term reads the mass
 //     straight from its own block (no copies), every successor is computed directly into the other set (no moves), the skip key
 //     `ka = cur + (span - 1) + "is a left child"` (one s_addc_u32) IS the other copy's `cur`;
@@ -967,34 +967,41 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
 #define K9_LOAD16(BLK, O) "s_load_dwordx16 " BLK ", %[node], %[off" O "]\n\t"
 #define K9_LOAD8(BLK, O) "s_load_dwordx8 " BLK ", %[node], %[off" O "]\n\t"
 
-// f64: A = s[48:63], B = s[64:79] (the highest SGPR the kernel touches decides its waves per SIMD: see below).  D = 3: x s[0:1] y s[2:3] z s[4:5] m s[6:7] w s[8:9] w2 s[10:11] v s[12:13] of the block;
+// f64: A = s[40:55], B = s[56:71] (the highest SGPR the kernel names decides its waves per SIMD: see below).  D = 3: x s[0:1] y s[2:3] z s[4:5] m s[6:7] w s[8:9] w2 s[10:11] v s[12:13] of the block;
 // D = 2: x s[0:1] y s[2:3] m s[4:5] w s[6:7] w2 s[8:9] v s[10:11].
 #define K9_PROGRAM_F64(Z, AX, AY, AZ, AM, AV, AVHI, BX, BY, BZ, BM, BV, BVHI, CNT_A, CNT_B)                               \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
-  K9_LOAD16("s[48:63]", "A")                                                                                              \
-  K9_STEP("A", "B", "6", "64", K9_LOAD16("s[64:79]", "B"), CNT_A, K9_TEST_F64(Z, AX, AY, AZ, AV),                         \
+  K9_LOAD16("s[40:55]", "A")                                                                                              \
+  K9_STEP("A", "B", "6", "64", K9_LOAD16("s[56:71]", "B"), CNT_A, K9_TEST_F64(Z, AX, AY, AZ, AV),                         \
           K9_EVAL_F64("Ad", Z, AM, AVHI, CNT_B), "")                                                                    \
-  K9_STEP("B", "A", "6", "64", K9_LOAD16("s[48:63]", "A"), CNT_A, K9_TEST_F64(Z, BX, BY, BZ, BV),                         \
+  K9_STEP("B", "A", "6", "64", K9_LOAD16("s[40:55]", "A"), CNT_A, K9_TEST_F64(Z, BX, BY, BZ, BV),                         \
           K9_EVAL_F64("Bd", Z, BM, BVHI, CNT_B), "s_branch .LK9topA%=\n")                                               \
-  K9_SKIP("A", "B", "6", "64", "6", K9_LOAD16("s[64:79]", "B"), K9_EVAL_F64("As", Z, AM, AVHI, CNT_B))                    \
-  K9_SKIP("B", "A", "6", "64", "6", K9_LOAD16("s[48:63]", "A"), K9_EVAL_F64("Bs", Z, BM, BVHI, CNT_B))                    \
+  K9_SKIP("A", "B", "6", "64", "6", K9_LOAD16("s[56:71]", "B"), K9_EVAL_F64("As", Z, AM, AVHI, CNT_B))                    \
+  K9_SKIP("B", "A", "6", "64", "6", K9_LOAD16("s[40:55]", "A"), K9_EVAL_F64("Bs", Z, BM, BVHI, CNT_B))                    \
   K9_NEAR_F64("Ad", Z, AM) K9_NEAR_F64("As", Z, AM) K9_NEAR_F64("Bd", Z, BM) K9_NEAR_F64("Bs", Z, BM)                     \
   ".LK9end%=:\n\t"                                                                                                        \
   "s_waitcnt lgkmcnt(0)\n\t" /* a record requested past the end of the walk: it must land before the registers are reused */ \
   "s_mov_b64 exec, %[sv]"
-// f32: A = s[64:71], B = s[80:87].  D = 3: x y z m w w2 v = s0..s6 of the block; D = 2: x y m w w2 v = s0..s5.
+// f32: A = s[56:63], B = s[64:71].  D = 3: x y z m w w2 v = s0..s6 of the block; D = 2: x y m w w2 v = s0..s5.
 #define K9_PROGRAM_F32(Z, AX, AY, AZ, AM, AV, BX, BY, BZ, BM, BV, CNT_A, CNT_B)                                           \
   "s_mov_b64 %[sv], exec\n\t"                                                                                             \
-  K9_LOAD8("s[64:71]", "A")                                                                                               \
-  K9_STEP("A", "B", "5", "32", K9_LOAD8("s[80:87]", "B"), CNT_A, K9_TEST_F32(Z, AX, AY, AZ, AV),                          \
+  K9_LOAD8("s[56:63]", "A")                                                                                               \
+  K9_STEP("A", "B", "5", "32", K9_LOAD8("s[64:71]", "B"), CNT_A, K9_TEST_F32(Z, AX, AY, AZ, AV),                          \
           K9_EVAL_F32("Ad", Z, AM, "", CNT_B), "")                                                                      \
-  K9_STEP("B", "A", "5", "32", K9_LOAD8("s[64:71]", "A"), CNT_A, K9_TEST_F32(Z, BX, BY, BZ, BV),                          \
+  K9_STEP("B", "A", "5", "32", K9_LOAD8("s[56:63]", "A"), CNT_A, K9_TEST_F32(Z, BX, BY, BZ, BV),                          \
           K9_EVAL_F32("Bd", Z, BM, "", CNT_B), "s_branch .LK9topA%=\n")                                                 \
-  K9_SKIP("A", "B", "5", "32", "5", K9_LOAD8("s[80:87]", "B"), K9_EVAL_F32("As", Z, AM, "", CNT_B))                       \
-  K9_SKIP("B", "A", "5", "32", "5", K9_LOAD8("s[64:71]", "A"), K9_EVAL_F32("Bs", Z, BM, "", CNT_B))                       \
+  K9_SKIP("A", "B", "5", "32", "5", K9_LOAD8("s[64:71]", "B"), K9_EVAL_F32("As", Z, AM, "", CNT_B))                       \
+  K9_SKIP("B", "A", "5", "32", "5", K9_LOAD8("s[56:63]", "A"), K9_EVAL_F32("Bs", Z, BM, "", CNT_B))                       \
   ".LK9end%=:\n\t"                                                                                                        \
   "s_waitcnt lgkmcnt(0)\n\t" /* a record requested past the end of the walk: it must land before the registers are reused */ \
   "s_mov_b64 exec, %[sv]"
+
+#ifdef NBODY_EXPERIMENTS
+// tools/k9_timeline.py: per work item of a sweep launch (start, end) in 100 MHz ticks and the item, three words per launch block
+__device__ unsigned long long* g_k9_timeline = nullptr;
+static unsigned long long* g_k9_timeline_host = nullptr;  // the same buffer, for nbody_exp_k9_timeline
+static size_t g_k9_timeline_words = 0;
+#endif
 
 template <typename T, int D, bool COUNT>
 __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<T>* __restrict__ node, T* __restrict__ a,
@@ -1017,6 +1024,9 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     lane_hi = lane_lo + 64u / parts - 1u;
     group /= parts;
   }
+#ifdef NBODY_EXPERIMENTS
+  const unsigned long long tl_start = g_k9_timeline ? wall_clock64() : 0ull;
+#endif
   const uint32_t local = group * 64u + threadIdx.x;
   const bool valid     = local < count && threadIdx.x >= lane_lo && threadIdx.x <= lane_hi;
   const uint32_t bi    = first + (valid ? local : 0u);
@@ -1036,7 +1046,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   uint32_t t1, t2, t3, cinc;
   uint64_t match, take, op, sv;
 #define K9_CLOBBER8                                                                                                        \
-  "vcc", "scc", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87"
+  "vcc", "scc", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
   if constexpr (sizeof(T) == 8) {
     const pair_consts<double> pc;
     double k0375 = 0.375, tiny = pair_math<double>::tiny, eps = DBL_EPSILON;
@@ -1054,15 +1064,18 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi),                  \
     [k0375] "s"(k0375), [m52] "s"(m52), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
     [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
-  : "vcc", "scc", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64",  \
-    "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79"
-    // The record blocks sit at s[48:79], not at the top of the file: a gfx9-class SIMD has 800 SGPRs, allocated in 16s, so a wave
-    // that touches s80 or above (+ VCC and the reserved pairs: > 96) leaves room for 7 waves per SIMD, not 8.  Round 4's first form
-    // had them at s[64:95] (next free SGPR 104: seven waves).
+  : "vcc", "scc", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56",  \
+    "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
+    // The record blocks sit at s[40:71]: the highest SGPR a wave names decides how many waves a SIMD holds, and the steps are NOT
+    // where the arithmetic puts them (800 SGPRs, granules of 16): measured with long one-wave blocks that name one high register
+    // (tools/microbench/cu_map.hip, blocks alive at once per SIMD): up to s71 EIGHT, s72 ... s88 seven, s95 and above six — 16 more
+    // SGPRs are held back per wave.  Round 4's first form had the blocks at s[64:95] (six waves, believed seven), its second at
+    // s[48:79] (SEVEN waves — 7168 items alive at once in tools/k9_timeline.py — believed eight); at s[40:71] the kernel's count is
+    // 78 with VCC and the reserved pairs and 8192 items are alive at once: config 4 6.38 -> 6.21 ms per traversal, float 4.49 -> 4.31.
 #define K9_REGS3                                                                                                           \
-  "s[48:49]", "s[50:51]", "s[52:53]", "s[54:55]", "s[60:61]", "s61", "s[64:65]", "s[66:67]", "s[68:69]", "s[70:71]", "s[76:77]", "s77"
+  "s[40:41]", "s[42:43]", "s[44:45]", "s[46:47]", "s[52:53]", "s53", "s[56:57]", "s[58:59]", "s[60:61]", "s[62:63]", "s[68:69]", "s69"
 #define K9_REGS2                                                                                                           \
-  "s[48:49]", "s[50:51]", "", "s[52:53]", "s[58:59]", "s59", "s[64:65]", "s[66:67]", "", "s[68:69]", "s[74:75]", "s75"
+  "s[40:41]", "s[42:43]", "", "s[44:45]", "s[50:51]", "s51", "s[56:57]", "s[58:59]", "", "s[60:61]", "s[66:67]", "s67"
     if constexpr (D == 3) {
       if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
       else asm volatile(K9_APPLY(K9_PROGRAM_F64, K9_KEEP, K9_REGS3, K9_NOCOUNT_A, "") K9_OPERANDS);
@@ -1086,8 +1099,8 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]),         \
     [tiny] "s"(tiny), [eps] "s"(eps), [bi] "v"(bi)                                                                         \
   : K9_CLOBBER8
-#define K9_REGS3 "s64", "s65", "s66", "s67", "s70", "s80", "s81", "s82", "s83", "s86"
-#define K9_REGS2 "s64", "s65", "", "s66", "s69", "s80", "s81", "", "s82", "s85"
+#define K9_REGS3 "s56", "s57", "s58", "s59", "s62", "s64", "s65", "s66", "s67", "s70"
+#define K9_REGS2 "s56", "s57", "", "s58", "s61", "s64", "s65", "", "s66", "s69"
     if constexpr (D == 3) {
       if constexpr (COUNT) asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_KEEP, K9_REGS3, K9_COUNT_A, K9_COUNT_B) K9_OPERANDS);
       else asm volatile(K9_APPLY(K9_PROGRAM_F32, K9_KEEP, K9_REGS3, K9_NOCOUNT_A, "") K9_OPERANDS);
@@ -1110,6 +1123,13 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
       counters[uint64_t(bi) * 4 + 3] = cb;
     }
   }
+#ifdef NBODY_EXPERIMENTS
+  if (g_k9_timeline && threadIdx.x == 0) {
+    g_k9_timeline[3 * size_t(blockIdx.x) + 0] = tl_start;
+    g_k9_timeline[3 * size_t(blockIdx.x) + 1] = wall_clock64();
+    g_k9_timeline[3 * size_t(blockIdx.x) + 2] = (1ull << 63) | (unsigned long long)(group) | ((unsigned long long)lane_lo << 32) | ((unsigned long long)lane_hi << 40);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1320,6 +1340,21 @@ static int force_run(nbody_bvh* t, const nbody_state* s, double theta, hipStream
 #define NB_IARGS                                                                                                             \
   dim3(wave_blocks), dim3(64), lds, st, node, static_cast<T*>(s->a), static_cast<const T*>(s->x), static_cast<T>(s->c), s->sz,     \
    s->first, s->count, t->nlevels, t->counters, items, nitems, stride, parts
+#ifdef NBODY_EXPERIMENTS
+    if (const char* e = getenv("NBODY_K9_TIMELINE"); e && e[0] == '1') {  // tools/k9_timeline.py
+      static unsigned long long* buf = nullptr;
+      static size_t cap = 0;
+      if (cap < 3 * size_t(wave_blocks)) {
+        if (buf) (void)hipFree(buf);
+        cap = 3 * size_t(wave_blocks);
+        NB_HIP(hipMalloc(&buf, cap * sizeof(unsigned long long)));
+        NB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_k9_timeline), &buf, sizeof buf));
+      }
+      NB_HIP(hipMemsetAsync(buf, 0, cap * sizeof(unsigned long long), st));
+      g_k9_timeline_host = buf;
+      g_k9_timeline_words = 3 * size_t(wave_blocks);
+    }
+#endif
     if (t->counters_on) hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, true>), NB_IARGS);
     else hipLaunchKernelGGL((bvh_force_sweep_isa_kernel<T, D, false>), NB_IARGS);
 #undef NB_IARGS
@@ -1614,3 +1649,13 @@ extern "C" int nbody_bvh_read(nbody_bvh* t, int what, void* host_out, size_t byt
     default: set_error("nbody_bvh_read: unknown what=%d", what); return NBODY_ERR_ARG;
   }
 }
+
+#ifdef NBODY_EXPERIMENTS
+// experiments library only (not in nbody_hip.h): the timeline of the last sweep launch made with NBODY_K9_TIMELINE=1
+extern "C" long long nbody_exp_k9_timeline(unsigned long long* out, size_t max_words) {
+  if (!nbody::g_k9_timeline_host || max_words < nbody::g_k9_timeline_words) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return -2;
+  if (hipMemcpy(out, nbody::g_k9_timeline_host, nbody::g_k9_timeline_words * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -3;
+  return (long long)nbody::g_k9_timeline_words;
+}
+#endif

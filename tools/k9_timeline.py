@@ -1,0 +1,64 @@
+"""Experiment (libnbody_hip_exp.so, NBODY_K9_TIMELINE=1): when every work item of ONE sweep launch at config 4 started and ended
+(s_memrealtime, 100 MHz), what the launch looks like over time, and a list-scheduling what-if with the measured durations:
+the order that ran, longest-first by the true durations, and longest-first by predictors a same-step pre-pass could compute
+(the group's bounding-box diagonal).  Durations are taken under the contention of the real launch (items in the tail ran alone
+and faster), so the what-if is indicative, as the same model was for round 2's kernel."""
+import os, sys, ctypes as C, heapq
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _experiments import load_package
+nb = load_package()
+n, theta = int(os.environ.get("K9_N", "1000000")), 0.5
+dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "galaxy", n))
+st, t = dev.state(), dev.bvh
+for _ in range(int(os.environ.get("K9_STEPS", "3"))):       # a few steps of the evolving system, as the step loop sees it
+    dev.bvh_force(theta); dev.accelerate_step()
+t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
+for _ in range(3):
+    t.compute_force(st, theta, dev.stream)
+dev.sync()
+os.environ["NBODY_K9_TIMELINE"] = "1"
+t.compute_force(st, theta, dev.stream); dev.sync()
+os.environ.pop("NBODY_K9_TIMELINE")
+L = nb.lib()
+L.nbody_exp_k9_timeline.restype = C.c_longlong
+buf = np.zeros(3 * (n // 64 + 4096) * 2, np.uint64)
+words = L.nbody_exp_k9_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.size))
+assert words > 0, words
+tl = buf[:words].reshape(-1, 3)
+ok = (tl[:, 2] >> np.uint64(63)) == 1
+tl = tl[ok]
+start, end = tl[:, 0].astype(np.int64), tl[:, 1].astype(np.int64)
+group = (tl[:, 2] & np.uint64(0xfffff)).astype(np.int64)
+lo = ((tl[:, 2] >> np.uint64(32)) & np.uint64(63)).astype(np.int64); hi = ((tl[:, 2] >> np.uint64(40)) & np.uint64(63)).astype(np.int64)
+t0 = start.min()
+start, end = (start - t0) * 0.01, (end - t0) * 0.01          # microseconds
+dur = end - start
+span = end.max()
+print(f"n = {n}: {len(dur)} work items ({int(((lo > 0) | (hi < 63)).sum())} of them half groups), launch {span / 1e3:.3f} ms from first start to last end")
+print(f"item durations (us): min {dur.min():.0f}  p10 {np.percentile(dur, 10):.0f}  median {np.median(dur):.0f}  p90 {np.percentile(dur, 90):.0f}  max {dur.max():.0f};  sum / 8192 slots = {dur.sum() / 8192 / 1e3:.3f} ms")
+ts = np.linspace(0, span, 41)
+running = [(int(((start <= x) & (end > x)).sum())) for x in ts]
+print("items running over the launch (41 samples):", " ".join(str(r) for r in running))
+half = next((x for x, r in zip(ts[::-1], running[::-1]) if r >= 4096), 0.0)
+print(f"last moment with >= 4096 items running: {half / 1e3:.3f} ms -> the drain takes {(span - half) / 1e3:.3f} ms; the last item started at {start.max() / 1e3:.3f} ms")
+
+def makespan(order, slots=8192):
+    heap = [0.0] * slots
+    for i in order:
+        heapq.heappush(heap, heapq.heappop(heap) + dur[i])
+    return max(heap)
+
+x = dev.download().x                                         # the state is in key order after the sort
+diag = np.zeros(len(dur))
+for i, (g, a, b) in enumerate(zip(group, lo, hi)):
+    p = x[g * 64 + a: min(n, g * 64 + b + 1)]
+    diag[i] = np.linalg.norm(p.max(axis=0) - p.min(axis=0)) if len(p) else 0.0
+orders = {"the order that ran (by start time)": np.argsort(start, kind="stable"),
+          "group index order": np.argsort(group * 64 + lo, kind="stable"),
+          "longest first, true durations": np.argsort(-dur, kind="stable"),
+          "longest first by the group's bounding-box diagonal": np.argsort(-diag, kind="stable"),
+          "shortest first (worst case)": np.argsort(dur, kind="stable")}
+print(f"list scheduling of the measured durations on 8192 slots (ms); correlation of the diagonal with the duration: {np.corrcoef(diag, dur)[0, 1]:.3f}")
+for name, o in orders.items():
+    print(f"    {name:55s} {makespan(o) / 1e3:.3f}")

@@ -24,6 +24,9 @@ timeout -k 10 300 python3 tools/k1_rule_instances.py > $O/k1_rule_instances.txt 
 if [ -f stdpar-nbody_amd/libnbody_hip_var_r3.so ] && [ -f stdpar-nbody_amd/libnbody_hip_var_r4head.so ]; then
   AB_CASES="f32:uniform:262144,f32:galaxy:262144,f32:uniform:100000,f64:uniform:65536,f64:galaxy:262144,f64:galaxy:1048576" timeout -k 10 600 python3 tools/ab_all_pairs.py libnbody_hip_var_r3.so libnbody_hip_var_r4head.so libnbody_hip.so > $O/ab_k1_r3_r4_r5.txt 2>&1; cat $O/ab_k1_r3_r4_r5.txt
 fi
+timeout -k 10 100 python3 tools/k9_timeline.py > $O/k9_timeline.txt 2>&1
+[ -f stdpar-nbody_amd/libnbody_hip_var_pre8.so ] && timeout -k 10 200 python3 tools/ab_k9.py > $O/ab_k9_waves.txt 2>&1
+[ -x tools/microbench/cu_map ] && timeout -k 10 60 ./tools/microbench/cu_map > $O/cu_map_microbench.txt 2>&1
 STEP_GRAPH_N=64,257,513,1000,1024,2048 timeout -k 10 200 python3 tools/time_step_graph.py > $O/step_graph_small.txt 2>&1; STEP_GRAPH_N=64,257,513,1000,1024,2048 timeout -k 10 200 python3 tools/time_step_graph.py float >> $O/step_graph_small.txt 2>&1
 if [ "$2" = "short" ]; then exit 0; fi
 echo "== matrix"; timeout -k 10 400 bash tools/benchmark.sh 200 > $O/benchmark.log 2> $O/benchmark.err; python3 tools/scrape_bench_log.py $O/benchmark.log > $O/benchmark.csv; cat $O/benchmark.csv

@@ -54,11 +54,25 @@ diag = np.zeros(len(dur))
 for i, (g, a, b) in enumerate(zip(group, lo, hi)):
     p = x[g * 64 + a: min(n, g * 64 + b + 1)]
     diag[i] = np.linalg.norm(p.max(axis=0) - p.min(axis=0)) if len(p) else 0.0
+# per-body walk lengths of THIS traversal (a counted launch): what the best possible per-body predictor would know
+t.enable_counters(True)
+t.compute_force(st, theta, dev.stream); dev.sync()
+cnt = t.read(5, dev.stream).reshape(-1, 4).astype(np.int64)
+t.enable_counters(False)
+body_len = cnt[:, 0] + cnt[:, 3]                              # nodes tested + body entries accepted: the entries the body stands on
+gmax, gsum = np.zeros(len(dur)), np.zeros(len(dur))
+for i, (g, a, b) in enumerate(zip(group, lo, hi)):
+    w = body_len[g * 64 + a: min(n, g * 64 + b + 1)]
+    gmax[i], gsum[i] = (w.max(), w.sum()) if len(w) else (0, 0)
+print(f"correlation with the duration: the longest walk of the item's bodies {np.corrcoef(gmax, dur)[0, 1]:.3f}, the sum of their walks {np.corrcoef(gsum, dur)[0, 1]:.3f}, "
+      f"longest walk x diagonal {np.corrcoef(gmax * (1 + diag), dur)[0, 1]:.3f}")
 orders = {"the order that ran (by start time)": np.argsort(start, kind="stable"),
+          "longest first by the longest walk of the item's bodies (this step's own counters: an upper bound for a per-body predictor)": np.argsort(-gmax, kind="stable"),
+          "longest first by the sum of the bodies' walks": np.argsort(-gsum, kind="stable"),
           "group index order": np.argsort(group * 64 + lo, kind="stable"),
           "longest first, true durations": np.argsort(-dur, kind="stable"),
           "longest first by the group's bounding-box diagonal": np.argsort(-diag, kind="stable"),
           "shortest first (worst case)": np.argsort(dur, kind="stable")}
 print(f"list scheduling of the measured durations on 8192 slots (ms); correlation of the diagonal with the duration: {np.corrcoef(diag, dur)[0, 1]:.3f}")
 for name, o in orders.items():
-    print(f"    {name:55s} {makespan(o) / 1e3:.3f}")
+    print(f"    {makespan(o) / 1e3:.3f}  {name}")

@@ -27,6 +27,7 @@ words = L.nbody_exp_k9_timeline(buf.ctypes.data_as(C.c_void_p), C.c_size_t(buf.s
 assert words > 0, words
 tl = buf[:words].reshape(-1, 3)
 ok = (tl[:, 2] >> np.uint64(63)) == 1
+block_id = np.arange(len(tl))[ok]                             # launch block index: list (XCD) = id % 8, slot in the list = id // 8
 tl = tl[ok]
 start, end = tl[:, 0].astype(np.int64), tl[:, 1].astype(np.int64)
 group = (tl[:, 2] & np.uint64(0xfffff)).astype(np.int64)
@@ -76,3 +77,22 @@ orders = {"the order that ran (by start time)": np.argsort(start, kind="stable")
 print(f"list scheduling of the measured durations on 8192 slots (ms); correlation of the diagonal with the duration: {np.corrcoef(diag, dur)[0, 1]:.3f}")
 for name, o in orders.items():
     print(f"    {makespan(o) / 1e3:.3f}  {name}")
+
+# What if the items that START LAST were swept as narrower lane ranges?  Slots are idle during the drain, so the extra work is free
+# there; a 32-lane sweep takes 0.86 of the 64-lane sweep's steps at config 4, a 16-lane sweep 0.77 (DESIGN_APPENDIX, round 2 data).
+slot = block_id // 8
+order_ran = np.argsort(start, kind="stable")
+print("what if the last fraction f of every XCD's list were cut into k lane ranges (durations x 0.86 for k = 2, x 0.77 for k = 4), list-scheduled in the order that ran:")
+for k, factor in ((2, 0.86), (4, 0.77)):
+    row = []
+    for f in (1 / 32, 1 / 16, 1 / 8, 1 / 4, 1 / 2):
+        heap = [0.0] * 8192
+        thr = np.quantile(slot, 1 - f)
+        for i in order_ran:
+            if slot[i] >= thr and lo[i] == 0 and hi[i] == 63:
+                for _ in range(k):
+                    heapq.heappush(heap, heapq.heappop(heap) + dur[i] * factor)
+            else:
+                heapq.heappush(heap, heapq.heappop(heap) + dur[i])
+        row.append(f"f = 1/{round(1 / f)}: {max(heap) / 1e3:.3f}")
+    print(f"    k = {k}: " + "   ".join(row) + f"   (none: {makespan(order_ran) / 1e3:.3f})")

@@ -2,8 +2,10 @@
 """Registers, LDS, scratch and the waves per SIMD they allow, for every kernel of a built library (read from the code object's
 metadata notes; no GPU needed).  usage: kernel_resources.py [lib.so] [name-filter ...]
 
-Waves per SIMD on gfx950 (512 VGPRs per lane and SIMD in the unified file, allocated in blocks of 8; 800 SGPRs per SIMD are no
-limit at <= 102 per wave): min(8, 512 // vgprs_rounded_up_to_8), accumulation registers included."""
+Waves per SIMD on gfx950: min(8, by VGPRs, by SGPRs).  VGPRs: 512 per lane and SIMD in the unified file, allocated in blocks of 8,
+accumulation registers included.  SGPRs: 800 per SIMD in granules of 16 with 16 MORE held back per wave — measured, round 5
+(tools/microbench/cu_map.hip: a kernel that names up to s71, sgpr_count <= 78, runs 8 waves per SIMD; up to s88 seven; above six):
+floor(800 / (sgpr_count rounded up to 16 + 16)).  A `*` marks kernels that the SGPRs hold below what their VGPRs allow."""
 import os
 import re
 import subprocess
@@ -65,9 +67,12 @@ def main():
         seen.add(n)
         v, a = int(k.get("vgpr_count", 0)), int(k.get("agpr_count", 0))
         tot = (v + a + 7) // 8 * 8
-        waves = min(8, 512 // tot) if tot else 8
-        print(f"{v:5d} {a:5d} {int(k.get('sgpr_count', 0)):5d} {int(k.get('group_segment_fixed_size', 0)):7d} "
-              f"{int(k.get('private_segment_fixed_size', 0)):7d} {waves:10d}  {n[:150]}")
+        by_v = min(8, 512 // tot) if tot else 8
+        sg = int(k.get("sgpr_count", 0))
+        by_s = min(8, 800 // ((sg + 15) // 16 * 16 + 16))
+        waves = min(by_v, by_s)
+        print(f"{v:5d} {a:5d} {sg:5d} {int(k.get('group_segment_fixed_size', 0)):7d} "
+              f"{int(k.get('private_segment_fixed_size', 0)):7d} {waves:9d}{'*' if by_s < by_v else ' '}  {n[:150]}")
 
 
 if __name__ == "__main__":

@@ -195,3 +195,20 @@ def test_hand_built_state_with_garbage_tuning_is_refused(nb):
     buf = ctypes.create_string_buffer(256)
     st.tuning = nb.tuning(4, 1, 1)
     assert L.nbody_all_pairs_describe(ctypes.byref(st), buf, ctypes.c_size_t(256)) == 0, L.nbody_last_error()
+
+
+def test_k9_sweep_fits_eight_waves_per_simd(nb):
+    """A wave that names an SGPR above s71 (sgpr_count > 78 with VCC and the reserved pairs) leaves room for seven waves per SIMD,
+    not eight (measured: tools/microbench/cu_map.hip; rounds 3-4 ran K9 at six and seven while believing seven and eight).  The
+    sweep's record blocks sit at s[40:71] for that reason; this holds the built kernels to the budget (metadata of the code object,
+    tools/kernel_resources.py), so that a change which nudges the compiler's own scalars upward cannot quietly cost the eighth wave."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"):
+        pytest.skip("llvm-readelf not available")
+    spec = importlib.util.spec_from_file_location("kernel_resources", os.path.join(ROOT, "tools", "kernel_resources.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ks = [k for k in mod.kernels(nb.LIB_PATH) if "bvh_force_sweep_isa_kernel" in k["symbol"]]
+    assert len(ks) == 8, len(ks)
+    for k in ks:
+        assert int(k["sgpr_count"]) <= 78 and int(k["vgpr_count"]) + int(k.get("agpr_count", 0)) <= 64, (k["symbol"], k["sgpr_count"], k["vgpr_count"])

@@ -651,10 +651,17 @@ def main():
         os._exit(3)
     handoff = {"failed": hand["failed"], "waves_that_waited": hand["waits"], "polls": hand["polls"]}
     if use_dist:
-        mine = torch.tensor([hand["waits"], hand["polls"]], dtype=torch.int64, device=red_dev)
+        # the status is read AFTER the window recomputations above (rank 0 has launched K1 again since the `bad` vote), so the
+        # failure flag travels with the counts: a sticky failure on any rank ends every rank without a result line
+        mine = torch.tensor([hand["waits"], hand["polls"], 1 if hand["failed"] else 0], dtype=torch.int64, device=red_dev)
         allh = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allh, mine)
-        handoff = {"failed": False, "waves_that_waited": [int(t[0]) for t in allh], "polls": [int(t[1]) for t in allh], "by": "rank"}
+        failed = [bool(int(t[2])) for t in allh]
+        if any(failed):
+            fail_all("a K1 chunk hand-off failed on rank(s) %s after the timed steps (this rank: %s): the run is void"
+                     % ([r for r, f in enumerate(failed) if f],
+                        "block %d chunk %d" % (hand["block"], hand["chunk"]) if hand["failed"] else "clean"))
+        handoff = {"failed": failed, "waves_that_waited": [int(t[0]) for t in allh], "polls": [int(t[1]) for t in allh], "by": "rank"}
 
     if rank == 0:
         value = n * args.steps / elapsed

@@ -318,11 +318,16 @@ constexpr int kSgprWaves = JS > kWaves ? JS : kWaves;  // waves per block of the
 //
 // If the assumption ever fails, the failure is LOUD (k1_status, nbody_all_pairs_status, nbody_stream_sync, nbody_download):
 //   * a wave that has polled h.spins times (kTurnSpins: minutes) gives up: it swaps kTurnPoison into the turn word, records
-//     (block, group, chunk) in the stream's sticky status block, and leaves `a` alone — unless the swap returned its own number
-//     (the turn came between the last poll and the swap: the total is this wave's, and it writes NaN);
-//   * every wave that finds kTurnPoison while polling leaves without touching `a`;
-//   * a turn is passed on with a compare-and-swap y -> y + 1; a predecessor that comes late finds the poison instead, so at that
-//     moment it is the only wave that will ever touch the group's total again, and it writes NaN over it.
+//     (block, group, chunk) in the stream's sticky status block and overwrites the group's total with NaN;
+//   * every wave that finds kTurnPoison while polling overwrites the total with NaN and leaves;
+//   * a turn is passed on with a compare-and-swap y -> y + 1; a holder that finds the poison instead writes NaN over what it has
+//     just added.
+//   EVERY wave that meets the poison writes NaN (round 6; the writes are idempotent), so the order in which they come does not
+//   matter: the last store to the group's rows is a NaN in every interleaving — a holder that was in the middle of its add when
+//   the poison arrived stores its finite sum, then fails its compare-and-swap and stores NaN behind it; a predecessor that had
+//   not even begun to poll when its successors gave up (the case this protocol exists for: a block started late or out of order)
+//   finds the poison at its first poll.  Until round 6 only the wave that lost the compare-and-swap wrote NaN, and that late
+//   predecessor left a finite partial sum s_0 + ... + s_{y'-1} behind, reported by the status word alone.
 //   So a poisoned group ends as NaN (never as a finite partial sum), and the host call that waits for the stream returns
 //   NBODY_ERR_STATE naming the block and the chunk.
 // The running total is read and written with agent-scope accesses (it changes hands between CUs and XCDs): the predecessor's
@@ -341,6 +346,7 @@ struct k1_handoff {
   k1_status* status;
   uint32_t spins;     // polls before a waiting wave gives up (kTurnSpins; lowered only by the experiments build's tests)
   uint32_t delay;     // s_sleep(127) rounds before a turn is passed on (0; the experiments build's tests make successors wait)
+  uint32_t late;      // s_sleep(127) rounds before chunk 1's waves look at the turn word at all (0; experiments: a block started late)
 };
 template <typename T, int D, int R, int JS, int RULE = 0>
 __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kernel(const src_rec<T, D>* __restrict__ packed,
@@ -468,34 +474,36 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   bool poisoned = false;
   if (y > 0 && h.turn != nullptr) {  // my turn?  (wave-uniform address: every lane reads the same value)
     uint32_t spins = 0, seen;
-    bool mine = true;
+    if (y == 1)
+      for (uint32_t d = 0; d < h.late; ++d) __builtin_amdgcn_s_sleep(127);  // 0 rounds, except in the hand-off tests of the experiments build
     while ((seen = __hip_atomic_load(tw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != y) {
-      if (seen == kTurnPoison) {  // somebody gave up on this group: the total is not mine to touch
-        mine = false;
+      if (seen == kTurnPoison) {  // somebody gave up on this group: nobody will add to its total again, NaN goes over it
+        poisoned = true;
         break;
       }
       if (++spins > h.spins) {  // give up (see above)
-        uint32_t old = 0;
         if (lane == 0) {
-          old = __hip_atomic_exchange(tw, kTurnPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_exchange(tw, kTurnPoison, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (atomicCAS(&h.status->err, 0u, 1u) == 0u) {
             h.status->block = blockIdx.x;
             h.status->group = uint32_t(tgroup);
             h.status->chunk = y;
           }
         }
-        old      = __builtin_amdgcn_readfirstlane(old);
-        mine     = old == y;
-        poisoned = true;
-        break;
+        poisoned = true;  // whatever the word held — this wave's own number (the turn came between the last poll and the swap), a
+        break;            // predecessor's that has yet to come, or poison already — the group's total is overwritten with NaN
       }
       __builtin_amdgcn_s_sleep(8);
     }
+    // The loads of the running total below must be ISSUED after the poll that saw the turn.  The accesses are relaxed agent-scope
+    // atomics (sc1: they bypass this XCD's L2), so nothing has to be invalidated; what is needed is that the compiler keeps them
+    // behind the loop — a wavefront-scope acquire fence says so and emits no instruction (tools/check_k1_handoff.py verifies in the
+    // built code object that every load of the total carries sc1 and follows the last poll).
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (spins && lane == 0) {
       atomicAdd(&h.status->polls, (unsigned long long)spins);
       atomicAdd(&h.status->waits, 1ull);
     }
-    if (!mine) return;
   }
   // The total's R * D * 64 scalars of this target group are contiguous in `a`: through LDS (the slices' partials are spent) every
   // lane takes scalars e = q * 64 + lane, so each access is one full-width coalesced instruction — per component the lanes would
@@ -543,6 +551,7 @@ __global__ __launch_bounds__(64 * kSgprWaves<JS>) void all_pairs_force_sgpr_kern
   if (y < last && !poisoned && h.turn != nullptr) {  // pass the turn on once the stores above have been acknowledged
     for (uint32_t d = 0; d < h.delay; ++d) __builtin_amdgcn_s_sleep(127);  // 0 rounds, except in the hand-off tests of the experiments build
     __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0): this wave's stores are at the agent's coherence point
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // and the compiler keeps them above the hand-over (no instruction)
     __builtin_amdgcn_wave_barrier();
     uint32_t held = y;
     if (lane == 0) {
@@ -598,10 +607,12 @@ int ap_scratch_get(hipStream_t st, int which, size_t bytes, void** out) {
   }
   void* fresh = nullptr;
   NB_HIP(hipMalloc(&fresh, bytes));  // on the stream's device: the caller holds a device_guard
-  if (which == 4 || which == 3) {    // the status block and the rule's ticket start at zero
-    if (hipError_t e = hipMemset(fresh, 0, bytes); e != hipSuccess) {
+  if (which == 4 || which == 3) {    // the status block and the rule's ticket start at zero: ordered on the stream that will use
+    // them (every launch that reads them is queued on `st` behind this call) — a synchronous memset would go through the legacy
+    // stream, which has no defined order with a non-blocking `st` and would invalidate another thread's global-mode capture
+    if (hipError_t e = hipMemsetAsync(fresh, 0, bytes, st); e != hipSuccess) {
       (void)hipFree(fresh);
-      return hip_fail(e, "hipMemset(K1 scratch)", __FILE__, __LINE__);
+      return hip_fail(e, "hipMemsetAsync(K1 scratch)", __FILE__, __LINE__);
     }
   }
   if (slot->buf[which].ptr) slot->retired.push_back(slot->buf[which].ptr);
@@ -775,7 +786,7 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
   constexpr int TB = (kSgprWaves<JS> / JS) * 64 * R;
   uint32_t blocks  = (s->count + TB - 1) / TB;
   if (blocks == 0) return NBODY_OK;
-  k1_handoff h{nullptr, nullptr, nullptr, kTurnSpins, 0u};
+  k1_handoff h{nullptr, nullptr, nullptr, kTurnSpins, 0u, 0u};
   if (plan.chunks > 1) {  // before anything is queued: a failed reservation leaves the stream untouched
     void* q = nullptr;
     if (int r = ap_scratch_get(st, 1, sizeof(uint32_t) * sgpr_turn_words<R, JS>(s->count), &q)) return r;
@@ -789,6 +800,7 @@ static int launch_all_pairs_sgpr(const nbody_state* s, const k1_plan& plan, hipS
     // -DNBODY_EXPERIMENTS builds only (tests/test_gpu_all_pairs.py: the hand-off made to wait, and made to fail)
     if (const char* e = experiment_env("NBODY_K1_TURN_SPINS")) h.spins = uint32_t(strtoul(e, nullptr, 10));
     if (const char* e = experiment_env("NBODY_K1_HANDOFF_DELAY")) h.delay = uint32_t(strtoul(e, nullptr, 10));
+    if (const char* e = experiment_env("NBODY_K1_HANDOFF_LATE")) h.late = uint32_t(strtoul(e, nullptr, 10));
     // timing experiment only (WRONG sums): no turn words — every chunk's block adds to whatever `a` holds without waiting
     if (const char* e = experiment_env("NBODY_K1_NO_HANDOFF"); e && e[0] == '1') h.turn = nullptr, h.sums = nullptr;
     if (const char* e = experiment_env("NBODY_K1_COLLECT"); e && e[0] == '0') h.sums = nullptr;  // experiments: turns at every size

@@ -104,3 +104,12 @@ def assert_frames_equal_as_multisets(got, want, rtol):
     key = lambda a: np.lexsort(np.round(a / (scale * 1e-9)).T[::-1])
     g, w = got[key(got)], want[key(want)]
     assert np.abs(g - w).max() <= rtol * scale, np.abs(g - w).max() / scale
+
+
+@pytest.fixture(scope="session")
+def golden_long_runs():
+    """100- and 1000-step runs of the real reference at N = 1024, 3D double (tests/golden/generate_golden_long.py): SURVEY §8(c)'s
+    criterion at its stated length, with the distance of the reference's own other builds beside every case."""
+    meta = json.load(open(os.path.join(GOLDEN, "long_runs_meta.json")))
+    data = np.load(os.path.join(GOLDEN, "long_runs.npz"))
+    return meta, data

@@ -136,6 +136,29 @@ def test_k9_step_program_never_leaves_a_record_request_in_flight(nb):
     assert missed == 0, f"{missed} of {tried} removed waits went unreported"
 
 
+def test_k1_handoff_loads_follow_the_poll_and_bypass_the_l2(nb):
+    """K1's running total changes hands between blocks through relaxed agent-scope atomics ordered by `s_waitcnt 0` — outside the HIP
+    memory model's letter, so the property is checked where it lives, in the built code object (tools/check_k1_handoff.py): every
+    load and store of the total carries sc1; every load of it sits behind the poll loop (the source pins that with a wavefront-scope
+    acquire fence) and nothing branches from the adding code back into the polls; the turn's compare-and-swap follows an
+    `s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)` with no memory instruction in between; the collecting form loads the sums behind its
+    ticket.  The checker must be ABLE to see each defect: an sc1 dropped from any access, a load of the total copied above the
+    polls, the wait before the hand-over removed — every mutation of every instantiation must be reported."""
+    import importlib.util
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("llvm-objdump not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    spec = importlib.util.spec_from_file_location("check_k1_handoff", os.path.join(ROOT, "tools", "check_k1_handoff.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    facts, problems = mod.check(nb.LIB_PATH)
+    assert len(facts) == 32, f"{len(facts)} instantiations of all_pairs_force_sgpr_kernel found, expected 32"
+    assert not problems, "\n".join(problems[:10])
+    assert all(p == 2 and loads >= 2 and stores == 2 * loads and swaps == 1 for p, loads, stores, swaps in facts.values()), facts
+    tried, missed = mod.self_test(nb.LIB_PATH)
+    assert tried >= 10 * len(facts) and missed == 0, f"{missed} of {tried} mutations went unreported"
+
+
 def test_no_unpadded_isa_hazards_in_the_code_object(nb):
     """hipcc pads the data hazards of its own instructions, not those inside or at the edge of an asm block (round 3: an asm
     v_readfirstlane_b32 directly behind the compiler's v_mov of its source read the register's previous content in three

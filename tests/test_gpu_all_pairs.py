@@ -723,7 +723,8 @@ def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
     and `a` bitwise equal to the undelayed run — for the whole system, for a rank window and with two targets per lane.
     (2) A turn that does not come within the budget (delay of milliseconds, NBODY_K1_TURN_SPINS = 3): nbody_stream_sync and
     nbody_download return NBODY_ERR_STATE naming block and chunk, the status block holds the failure, and EVERY row of `a` is either
-    NaN or bitwise the right value — never a finite partial sum.  (3) The flag is sticky until cleared; after the clear the same
+    NaN or bitwise the right value — never a finite partial sum — both when the holder of the turn is late in passing it on and
+    (round 6) when a predecessor has not begun to poll at all while its successors give up.  (3) The flag is sticky until cleared; after the clear the same
     context computes the right forces again."""
     import subprocess, sys, textwrap
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -786,6 +787,33 @@ def test_k1_handoff_made_to_wait_and_made_to_fail(dtype):
         assert np.array_equal(hs.a[~bad], a0[~bad]), "a finite row differs from the undisturbed run"
         assert np.isnan(hs.a[bad]).all(), "a row is partly NaN"
         print("failed as it should:", int(bad.sum()), "of", n, "rows NaN;", st)
+        dev.close()
+        # the case the poison exists for (round 6): a predecessor that has not even begun to poll when its successors give up.  Chunk
+        # 1's waves sleep before their FIRST look at the turn word (NBODY_K1_HANDOFF_LATE); chunk 0 has handed on at once, so the
+        # word holds 1 while chunks 2..15 run out of polls and swap the poison in over it; chunk 1 then finds the poison at its first
+        # poll.  Until round 6 both kinds of wave left `a` alone and the rows kept the finite partial sum s_0: now each writes NaN.
+        for k in ("NBODY_K1_HANDOFF_DELAY", "NBODY_K1_TURN_SPINS", "NBODY_K1_COLLECT"):
+            os.environ.pop(k, None)
+        os.environ.update(NBODY_K1_HANDOFF_LATE="3000", NBODY_K1_TURN_SPINS="3", NBODY_K1_COLLECT="0")
+        dev = nb.DeviceSystem.from_host(nb.build_model(dtype, 3, "galaxy", n))
+        dev.all_pairs_force()
+        st = nb.all_pairs_status(dev.stream, check=False)
+        assert st["failed"] and st["rc"] == 3 and st["chunk"] >= 2, st
+        hs = nb.HostSystem(dtype, 3, n)
+        try:
+            dev.download(hs)
+            raise SystemExit("nbody_download returned success after a failed hand-off (late predecessor)")
+        except nb.NbodyError:
+            pass
+        bad = np.isnan(hs.a).any(axis=1)
+        assert bad.sum() >= n // 2, ("a late predecessor poisoned almost nothing", int(bad.sum()))
+        assert np.array_equal(hs.a[~bad], a0[~bad]), "late predecessor: a finite row differs from the undisturbed run"
+        assert np.isnan(hs.a[bad]).all(), "late predecessor: a row is partly NaN"
+        print("late predecessor:", int(bad.sum()), "of", n, "rows NaN;", st)
+        os.environ.pop("NBODY_K1_HANDOFF_LATE")
+        os.environ.update(NBODY_K1_HANDOFF_DELAY="3000", NBODY_K1_TURN_SPINS="3", NBODY_K1_COLLECT="0")
+        nb.all_pairs_status(dev.stream, clear=True, check=False)
+        dev.all_pairs_force()   # the first failure again, on this context: the sticky flag and the recovery are checked on it below
         # sticky, then cleared; the context works again
         os.environ.pop("NBODY_K1_HANDOFF_DELAY"); os.environ.pop("NBODY_K1_TURN_SPINS"); os.environ.pop("NBODY_K1_COLLECT")
         try:

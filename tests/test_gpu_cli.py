@@ -296,3 +296,57 @@ def test_config2_command_as_written(nb, oracle):
     nb.run(dev, "all-pairs", 100)
     assert final == oracle.format_state_rows(dev.download())
     dev.close()
+
+
+def test_reference_program_with_the_backend_dropped_in(oracle, golden_print_state, golden_positions):
+    """oracle/_ref/nbody_ref_hip_d{2,3} = the reference's UNMODIFIED main.cpp (CLI, generators, run_simulation, run_all_pairs, Saver,
+    print) + the stub of INTEGRATION.md (examples/hip_backend.h), built by `make -C oracle ref_hip` in the build container
+    (tests/test_integration_stub.py) — here it RUNS: row (b)'s binding meets the reference on the GPU.
+      * all-pairs: the reference's own step driver with the GPU force as its Force&& f (src/all_pairs.h:52-53,77,88) — every
+        double case prints the reference's golden text, start and final; --save all --csv-detailed writes the reference's frames;
+      * NBODY_HIP_RESIDENT=1: the device-resident loop of the stub (force phases + leapfrog on the GPU) for all-pairs, bvh and
+        octree — the reference's golden final rows again."""
+    exe = {d: os.path.join(ROOT, "oracle", "_ref", f"nbody_ref_hip_d{d}") for d in (2, 3)}
+    if not all(os.path.exists(e) for e in exe.values()):
+        pytest.skip("oracle/_ref/nbody_ref_hip_d* not built (make -C oracle ref_hip needs /root/reference)")
+
+    def run(dim, args, cwd=None, resident=False):
+        env = dict(os.environ)
+        env.pop("NBODY_HIP_RESIDENT", None)
+        if resident:
+            env["NBODY_HIP_RESIDENT"] = "1"
+        return subprocess.run([exe[dim]] + [str(a) for a in args], cwd=cwd, capture_output=True, text=True, timeout=600, env=env)
+
+    thin = resident = 0
+    for name, case in golden_print_state.items():
+        if case["precision"] != "double" or case["algorithm"] == "all-pairs-collapsed":
+            continue
+        for res in (False, True):
+            if not res and case["algorithm"] != "all-pairs":
+                continue
+            r = run(case["dim"], case["args"], resident=res)
+            assert r.returncode == 0, (name, r.stderr)
+            start, final = oracle.parse_print_state(r.stdout)
+            assert start == case["start"], f"{name}: starting state"
+            bad = [i for i, (a, b) in enumerate(zip(final, case["final"])) if a != b]
+            assert len(final) == len(case["final"]) and not bad, f"{name} resident={res}: {len(bad)} final rows differ"
+            assert re.search(r"Done simulation\nTotal time: \d+\.\d\d ms\n", r.stdout)
+            thin, resident = thin + (not res), resident + res
+    assert thin >= 12 and resident >= 36
+    # the reference's Saver and CSV row under the reference's own driver, forces from the GPU
+    meta, data = golden_positions
+    name = "d3_double_all-pairs_galaxy_n1024_s20"
+    case, ref = meta[name], data[name + "__frames"]
+    with tempfile.TemporaryDirectory() as d:
+        r = run(3, ["-n", 1024, "-s", 20, "--precision", "double", "--algorithm", "all-pairs", "--workload", "galaxy", "--save", "pos",
+                    "--csv-detailed"], cwd=d)
+        assert r.returncode == 0, r.stderr
+        assert re.fullmatch(r"all-pairs,3,64,20,1024,\d+\.\d\d,\d+\.\d\d,\d+\.\d\d", r.stdout.strip())
+        frames, hdr_steps = oracle.read_positions_bin(os.path.join(d, "positions.bin"))
+    assert frames.shape == (21, 1024, 3) and hdr_steps == 20
+    assert np.array_equal(frames[0], ref[0])
+    for k, fid in enumerate(case["frame_ids"]):
+        assert np.abs(frames[fid] - ref[k]).max() <= 1e-11 * np.abs(ref[0]).max(), fid
+    # a backend error ends the program the reference's way: message on stderr, EXIT_FAILURE
+    r = run(3, ["-n", 100, "--algorithm", "bvh", "--precision", "double"])
+    assert r.returncode != 0 and "NBODY_HIP_RESIDENT" in r.stderr

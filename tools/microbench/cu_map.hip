@@ -15,6 +15,9 @@ __global__ __launch_bounds__(BS) void spin(unsigned long long* t, unsigned* id, 
   float v = threadIdx.x;
   for (int i = 0; i < iters; ++i) v = __builtin_fmaf(v, 1.0001f, 0.5f);
   if constexpr (TOP == 71) asm volatile("s_mov_b32 s71, 0" ::: "s71");
+  if constexpr (TOP == 72) asm volatile("s_mov_b32 s72, 0" ::: "s72");
+  if constexpr (TOP == 73) asm volatile("s_mov_b32 s73, 0" ::: "s73");
+  if constexpr (TOP == 74) asm volatile("s_mov_b32 s74, 0" ::: "s74");
   if constexpr (TOP == 79) asm volatile("s_mov_b32 s79, 0" ::: "s79");
   if constexpr (TOP == 80) asm volatile("s_mov_b32 s80, 0" ::: "s80");
   if constexpr (TOP == 87) asm volatile("s_mov_b32 s87, 0" ::: "s87");
@@ -84,6 +87,9 @@ void run() {
 int main() {
   run<64>();
   run<64, 71>();
+  run<64, 72>();
+  run<64, 73>();
+  run<64, 74>();
   run<64, 79>();
   run<64, 80>();
   run<64, 87>();

@@ -43,11 +43,10 @@ def load_package():
     return mod
 
 
-def cpu_baseline(n, hs, target_seconds=15.0):
-    """Time the oracle's all-pairs loop (reference algorithm, src/all_pairs.h:14-27) on the host cores for a
-    bounded sample of target bodies against all n sources.  Built with the reference's own CPU flags
-    (-Ofast -march=native, ci/run:112-113) and parallelised over targets with OpenMP on every core."""
-    import numpy as np
+def fast_oracle():
+    """(ctypes library, build string, cores): the oracle's C restatement built with the reference's own CPU flags (-Ofast
+    -march=native, ci/run:112-113), OpenMP over every core the cgroup grants.  TEST INFRASTRUCTURE used as the reported CPU
+    baseline only — nothing of it is on the measured GPU path."""
     src = os.path.join(ROOT, "oracle", "nbody_oracle.c")
     tmp = tempfile.mkdtemp(prefix="nbody_cpu_")
     so = os.path.join(tmp, "liboracle_fast.so")
@@ -68,7 +67,36 @@ def cpu_baseline(n, hs, target_seconds=15.0):
     except Exception:
         pass
     os.environ["OMP_NUM_THREADS"] = str(cores)
-    L = C.CDLL(so)
+    return C.CDLL(so), build, cores
+
+
+def reference_serial_baseline():
+    """The REAL reference (oracle/_ref/nbody_ref_d3: /root/reference compiled unmodified, g++ -O2, PSTL's serial backend because the
+    image has no TBB headers) timed on ONE host core on a bounded run: all-pairs 3D double galaxy, -n 8192 -s 14 --csv-total, i.e.
+    10 warm-up and 4 timed steps (src/all_pairs.h:86-97); None where the binary is absent."""
+    exe = os.path.join(ROOT, "oracle", "_ref", "nbody_ref_d3")
+    if not os.path.exists(exe):
+        return None
+    n, steps = 8192, 14
+    try:
+        out = subprocess.run([exe, "-n", str(n), "-s", str(steps), "--precision", "double", "--algorithm", "all-pairs", "--workload",
+                              "galaxy", "--csv-total"], capture_output=True, text=True, timeout=300, check=True).stdout
+        total_s = float(out.strip().splitlines()[-1].split(",")[5])
+    except Exception as ex:
+        return {"failed": str(ex)}
+    timed = steps - 10
+    return {"value": n * timed / total_s, "unit": "body-steps/s", "cores": 1, "kind": "reference",
+            "interactions_per_s": n * (n - 1) * timed / total_s,
+            "sample": f"oracle/_ref/nbody_ref_d3 (the unmodified reference, g++ -O2, serial PSTL) -n {n} -s {steps} --csv-total: "
+                      f"{timed} timed steps in {total_s:.2f} s"}
+
+
+def cpu_baseline(n, hs, target_seconds=15.0):
+    """Time the oracle's all-pairs loop (reference algorithm, src/all_pairs.h:14-27) on the host cores for a
+    bounded sample of target bodies against all n sources.  Built with the reference's own CPU flags
+    (-Ofast -march=native, ci/run:112-113) and parallelised over targets with OpenMP on every core."""
+    import numpy as np
+    L, build, cores = fast_oracle()
     a = np.zeros((n, 3), np.float64)
 
     def run(count):
@@ -85,7 +113,26 @@ def cpu_baseline(n, hs, target_seconds=15.0):
     t = run(count)
     return {"value": count / t, "unit": "body-steps/s", "cores": cores, "kind": "port",
             "sample": f"{count} of {n} target bodies x all {n} sources, one force pass, {t:.1f} s, {build}",
-            "interactions_per_s": count * (n - 1) / t}
+            "interactions_per_s": count * (n - 1) / t,
+            "reference_serial": reference_serial_baseline()}
+
+
+def config1_cpu_leg(nb):
+    """BASELINE.json configs[0] on the host, WHOLE: all-pairs 2D float, -n 10000 -s 5 (the config that names the CPU path; 10
+    executed steps) through the CPU port — force (src/all_pairs.h:14-27) + leapfrog (src/system.h:52-60) per step."""
+    import numpy as np
+    L, build, cores = fast_oracle()
+    hs = nb.build_model(nb.F32, 2, "uniform", 10000)
+    n = hs.n
+    p = lambda arr: arr.ctypes.data_as(C.c_void_p)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        assert L.oracle_all_pairs_force(0, 2, p(hs.m), p(hs.x), p(hs.a), C.c_double(hs.c), C.c_uint32(n), C.c_uint32(0), C.c_uint32(n)) == 0
+        assert L.oracle_accelerate_step(0, 2, p(hs.x), p(hs.v), p(hs.a), p(hs.ao), C.c_double(hs.dt), C.c_uint32(n)) == 0
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    assert np.isfinite(hs.x).all()
+    return {"cpu_ms_per_step": ms, "cpu_cores": cores, "cpu_kind": "port", "cpu_build": build,
+            "cpu_body_steps_per_s": n / (ms * 1e-3), "cpu_sample": "the whole config: 10 steps x 10^8 ordered pairs"}
 
 
 class Telemetry:
@@ -198,9 +245,18 @@ def committed_config_evidence(name, sha):
         busy = c["SQ_ACTIVE_INST_VALU"] * 4.0 / (cycles * 1024)              # quad-cycles -> cycles, 1024 SIMDs
         lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64.0) if c.get("SQ_THREAD_CYCLES_VALU") else None
         traffic = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0 if "FETCH_SIZE" in c and "WRITE_SIZE" in c else None
+        # rocprofv3's VALUBusy formula prices every VALU instruction at 4 cycles (SQ_ACTIVE_INST_VALU is in quad-cycles).  That is the
+        # issue cost of an f64 instruction; an f32 instruction issues in 2.6 (profiles/r01_valu_rates_microbench.txt), so for a kernel
+        # of f32 instructions the formula exceeds 1 and is no fraction: the raw ratio is published under its own name and the
+        # fraction is withheld
+        is_frac = busy <= 1.0
         return {"source": os.path.relpath(path, ROOT) + " (rocprofv3 --pmc, separate passes; stamped with this library's source hash)",
-                "kernel": c.get("kernel"), "valu_busy_frac": busy, "valu_lanes_active_frac": lanes,
-                "valu_issue_frac": busy * lanes if lanes is not None else None,
+                "kernel": c.get("kernel"), "valu_busy_frac": busy if is_frac else None,
+                "valu_active_quad_cycles_x4_per_simd_cycle": busy,
+                "valu_busy_note": None if is_frac else "SQ_ACTIVE_INST_VALU x 4 / (cycles x SIMDs) counts 4 cycles per instruction; f32 "
+                                                        "instructions issue in ~2.6, so this ratio is not a fraction for an f32 kernel",
+                "valu_lanes_active_frac": lanes,
+                "valu_issue_frac": busy * lanes if (lanes is not None and is_frac) else None,
                 "valu_insts": c.get("SQ_INSTS_VALU"), "salu_insts": c.get("SQ_INSTS_SALU"),
                 "hbm_traffic_bytes_per_launch": traffic, "duration_ms_in_profiled_pass": c.get("duration_ns", 0) / 1e6 or None}
     return None
@@ -240,6 +296,34 @@ def other_configs(nb, torch):
         g.close()
         return ms
 
+    # configs[0]: all-pairs 2D float, -n 10000 -s 5 (uniform): the config that names the CPU path and the reference matrix's
+    # sequential size (ci/benchmark:64,137).  -s 5 in the default mode executes max(steps, warm-up) = 10 steps: those ten,
+    # replayed from the recorded step after one untimed launch.  Both legs: the GPU's, and the CPU port over the WHOLE config.
+    n = 10000
+    dev = nb.DeviceSystem.from_host(nb.build_model(nb.F32, 2, "uniform", n))
+    dev.all_pairs_force(); dev.sync()
+    g = nb.StepGraph(dev, lambda: (dev.all_pairs_force(), dev.accelerate_step()))
+    g.launch(); dev.sync()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        g.launch()
+    dev.sync()
+    ms = (time.perf_counter() - t0) / 10 * 1e3
+    g.close()
+    k_ms = events_around(dev, dev.all_pairs_force, 20, between=dev.accelerate_step)
+    tf = 14.0 * n * (n - 1) / (k_ms * 1e-3) / 1e12          # 14 flop per ordered pair in 2D
+    entry = {"workload": "all-pairs 2D float, -n 10000 -s 5, uniform, 1 GPU: the 10 steps the default mode executes, recorded step",
+             "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3), "kernel": nb.describe_all_pairs(dev.state()), "avg_kernel_ms": k_ms,
+             "avg_kernel_how": "HIP events around nbody_all_pairs_force (pre-pass + K1) in 20 further steps",
+             "bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_PEAK_TFLOPS,
+             "note": "157 target blocks x 16 chunks on 1024 block slots: a launch-shape loss, not a kernel loss"}
+    dev.close()
+    try:
+        entry.update(config1_cpu_leg(nb))
+    except Exception as ex:
+        entry["cpu_failed"] = str(ex)
+    out.append(entry)
+
     # configs[1]: all-pairs 3D double, -n 65536 -s 100 (no workload flag: the reference's default, uniform)
     n = 65536
     dev = nb.DeviceSystem.from_host(nb.build_model(nb.F64, 3, "uniform", n))
@@ -265,7 +349,7 @@ def other_configs(nb, torch):
     tf = FLOP_PER_INTERACTION * n * (n - 1) / (k_ms * 1e-3) / 1e12
     ev = committed_config_evidence("k2_config3", source_sha("all_pairs.hip", "common.hpp"))
     out.append({"workload": "all-pairs-collapsed 3D float, -n 262144 -s 20, uniform, 1 GPU: steps 11-20 of the recorded step",
-                "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3), "kernel": "all_pairs_collapsed_kernel<float,3> (+ collapsed_reset_kernel)",
+                "ms_per_step": ms, "body_steps_per_s": n / (ms * 1e-3), "kernel": "all_pairs_collapsed_stream_kernel<8> (float 3D: a wave owns 16 targets for its source chunk; + collapsed_reset_pack_kernel)",
                 "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_all_pairs_collapsed_force in steps 21-30",
                 "bound": "valu_fp32", "achieved": tf, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP32_VECTOR_PEAK_TFLOPS,
                 "rocprof": ev})
@@ -294,11 +378,18 @@ def other_configs(nb, torch):
                 "avg_kernel_ms": k_ms, "avg_kernel_how": "HIP events around nbody_bvh_compute_force in steps 21-30 of the evolving system (the work-item "
                                                                 "kernel 36 us + the sweep; + a 22-us threshold rewrite, which an eager traversal of a tree "
                                                                 "that has been recorded always makes)",
-                "bound": "valu_issue", "node_tests_per_s": node_tests / (k_ms * 1e-3), "node_tests_per_body": node_tests / n,
+                "bound": "valu_fp64", "node_tests_per_s": node_tests / (k_ms * 1e-3), "node_tests_per_body": node_tests / n,
                 "force_terms_per_body": terms / n,
-                "frac": ev["valu_issue_frac"] if ev else None,
-                "frac_is": "VALU busy x lanes active (rocprofv3 PMC of this kernel): the share of the vector issue slots that do a body's work; "
-                           "null unless a committed PMC summary carries this library's source hash",
+                # frac means ONE thing in this list: achieved / peak.  Algorithmic flop of a traversal: 20 per force term (K1's pair
+                # term) + 11 per node test (3 sub, 3 mul + 2 add for d^2, the product theta^2 * d^2, the compare, the
+                # square of the width: src/bvh.h:246-248, 297-308)
+                "achieved": (20.0 * terms + 11.0 * node_tests) / (k_ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": (20.0 * terms + 11.0 * node_tests) / (k_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "flop_model": "20 x force terms + 11 x node tests per body",
+                "valu_issue_frac": ev["valu_issue_frac"] if ev else None,
+                "valu_issue_frac_is": "VALU busy x lanes active (rocprofv3 PMC of this kernel): the share of the vector issue slots that do a "
+                                      "body's work — what actually bounds a divergent tree walk; null unless a committed PMC summary carries "
+                                      "this library's source hash",
                 "rocprof": ev,
                 "not_the_bound": {"hbm_cold_bytes_per_s": cold_bytes / (k_ms * 1e-3), "hbm_peak_bytes_per_s": 8.0e12,
                                   "why": "SURVEY 8(d) prices K9 as if every node test fetched its 40 B from HBM: that is %.1f TB/s here, above "

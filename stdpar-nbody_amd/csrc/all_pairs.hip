@@ -908,7 +908,7 @@ static int all_pairs_describe(const nbody_state* s, char* out, size_t len) {
 int ap_scratch_reserve(hipStream_t st, const nbody_state* s) {
   void* q             = nullptr;
   const size_t tsz    = s->dtype == NBODY_F32 ? 4 : 8;
-  const size_t padded = (size_t(s->sz) + kTileJ - 1) / kTileJ * kTileJ;
+  const size_t padded = (size_t(s->sz) + 2 * kTileJ - 1) / (2 * kTileJ) * (2 * kTileJ);  // K1 needs whole tiles, the streamed K2 pairs of them
   if (int r = ap_scratch_get(st, 0, 4 * tsz * padded, &q)) return r;
   if (int r = ap_scratch_get(st, 3, ap_rule_bytes(s->sz, s->dim), &q)) return r;
   return dispatch(s->dtype, s->dim, [&](auto tg) {
@@ -1075,8 +1075,76 @@ __device__ __forceinline__ T transpose_reduce(T (&p)[NT], int lane) {
   return v;
 }
 
+// K2's float pair (3D), scheduled by hand (round 6).  hipcc emits the pair as ONE dependent chain — sub, fma, fma, fma, rsq,
+// s_nop, mul, fma, rcp, s_nop, mul, fma x 3: every instruction waits for the one before it and each transcendental is followed
+// by a wait state (239 s_nop per 128 pairs) — and its own interleavings of two or four chains put v_rsq_f32 and v_rcp_f32 back
+// to back and lost (28.7 against 24.05 ms at config 3, rounds 2 and 5).  Here pair p's head (differences, r^2, rsq) is
+// interleaved with pair p - 1's tail (r^2 y, + eps, rcp, x m, three accumulations): the same fourteen instructions, the same
+// operations on the same operands in the same order per accumulator (bitwise what pair_math<float>::weight gives), no wait
+// state, every transcendental at least three instructions ahead of its consumer and seven behind the other one.
+// The carried state (the last pair's differences, r^2 and rsq) lives in VGPRs between the blocks.
+struct k2_carry {
+  float dx, dy, dz, r2, y;
+};
+__device__ __forceinline__ k2_carry k2_pair_head(const src_rec<float, 3>& s, const float (&xg)[3]) {
+  k2_carry n;
+  asm volatile(
+      "v_subrev_f32 %[dx], %[X], %[sx]\n\t"
+      "v_subrev_f32 %[dy], %[Y], %[sy]\n\t"
+      "v_subrev_f32 %[dz], %[Z], %[sz]\n\t"
+      "v_fmaak_f32 %[r2], %[dx], %[dx], 0x2081cea\n\t"   // pair_math<float>::tiny
+      "v_fmac_f32 %[r2], %[dy], %[dy]\n\t"
+      "v_fmac_f32 %[r2], %[dz], %[dz]\n\t"
+      "v_rsq_f32 %[y], %[r2]\n\t"
+      "s_nop 0"   // the consumer may be the very next instruction (the tail of a block of one pair)
+      : [dx] "=&v"(n.dx), [dy] "=&v"(n.dy), [dz] "=&v"(n.dz), [r2] "=&v"(n.r2), [y] "=&v"(n.y)
+      : [sx] "v"(s.p[0]), [sy] "v"(s.p[1]), [sz] "v"(s.p[2]), [X] "s"(xg[0]), [Y] "s"(xg[1]), [Z] "s"(xg[2]));
+  return n;
+}
+// head of the pair (s, xg) + tail of the carried pair: its weight r2 -> m / (r2 * (r2 * y) + eps), accumulated into (ax, ay, az)
+__device__ __forceinline__ k2_carry k2_pair_step(const src_rec<float, 3>& s, const float (&xg)[3], float mp, const k2_carry& c,
+                                                 float& ax, float& ay, float& az) {
+  k2_carry n;
+  float t;
+  asm volatile(
+      "v_mul_f32 %[t], %[r2p], %[yp]\n\t"
+      "v_subrev_f32 %[dx], %[X], %[sx]\n\t"
+      "v_fmaak_f32 %[t], %[r2p], %[t], 0x34000000\n\t"   // FLT_EPSILON
+      "v_subrev_f32 %[dy], %[Y], %[sy]\n\t"
+      "v_subrev_f32 %[dz], %[Z], %[sz]\n\t"
+      "v_rcp_f32 %[t], %[t]\n\t"
+      "v_fmaak_f32 %[r2], %[dx], %[dx], 0x2081cea\n\t"
+      "v_fmac_f32 %[r2], %[dy], %[dy]\n\t"
+      "v_fmac_f32 %[r2], %[dz], %[dz]\n\t"
+      "v_mul_f32 %[t], %[mp], %[t]\n\t"
+      "v_rsq_f32 %[y], %[r2]\n\t"
+      "v_fmac_f32 %[ax], %[t], %[dxp]\n\t"
+      "v_fmac_f32 %[ay], %[t], %[dyp]\n\t"
+      "v_fmac_f32 %[az], %[t], %[dzp]"
+      : [dx] "=&v"(n.dx), [dy] "=&v"(n.dy), [dz] "=&v"(n.dz), [r2] "=&v"(n.r2), [y] "=&v"(n.y), [t] "=&v"(t), [ax] "+v"(ax),
+        [ay] "+v"(ay), [az] "+v"(az)
+      : [sx] "v"(s.p[0]), [sy] "v"(s.p[1]), [sz] "v"(s.p[2]), [X] "s"(xg[0]), [Y] "s"(xg[1]), [Z] "s"(xg[2]), [mp] "v"(mp),
+        [r2p] "v"(c.r2), [yp] "v"(c.y), [dxp] "v"(c.dx), [dyp] "v"(c.dy), [dzp] "v"(c.dz));
+  return n;
+}
+__device__ __forceinline__ void k2_pair_tail(float mp, const k2_carry& c, float& ax, float& ay, float& az) {
+  float t;
+  asm volatile(
+      "v_mul_f32 %[t], %[r2p], %[yp]\n\t"
+      "v_fmaak_f32 %[t], %[r2p], %[t], 0x34000000\n\t"
+      "v_rcp_f32 %[t], %[t]\n\t"
+      "s_nop 0\n\t"
+      "v_mul_f32 %[t], %[mp], %[t]\n\t"
+      "v_fmac_f32 %[ax], %[t], %[dxp]\n\t"
+      "v_fmac_f32 %[ay], %[t], %[dyp]\n\t"
+      "v_fmac_f32 %[az], %[t], %[dzp]"
+      : [t] "=&v"(t), [ax] "+v"(ax), [ay] "+v"(ay), [az] "+v"(az)
+      : [mp] "v"(mp), [r2p] "v"(c.r2), [yp] "v"(c.y), [dxp] "v"(c.dx), [dyp] "v"(c.dy), [dzp] "v"(c.dz));
+}
+
 // NT: targets reduced together (NT * D partial sums live per lane); KS: source records per lane held in registers at a
 // time; NB: independent pair chains in flight
+// (NB = 0: float 3D only — the pair scheduled by hand, k2_pair_step above; the form that ships for config 3)
 template <typename T, int D, int NT, int KS, int NB>
 __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __restrict__ m, const T* __restrict__ x,
                                                                      T* __restrict__ a, T c, uint32_t sz,
@@ -1152,6 +1220,17 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
           rec_t src[KS];
 #pragma unroll
           for (int q = 0; q < KS; ++q) src[q] = tile[(sub * KS + q) * 64 + lane];
+          if constexpr (NB == 0) {
+            static_assert(NB != 0 || (sizeof(T) == 4 && D == 3), "the hand-scheduled pair is float 3D");
+            // the NT * KS pairs of this batch as one software pipeline: pair p = (target p / KS, source p % KS)
+            k2_carry cy = k2_pair_head(src[0], xg[0]);
+#pragma unroll
+            for (int p = 1; p < NT * KS; ++p) {
+              const int tp = (p - 1) / KS;
+              cy = k2_pair_step(src[p % KS], xg[p / KS], src[(p - 1) % KS].m, cy, part[0][tp], part[1][tp], part[2][tp]);
+            }
+            k2_pair_tail(src[KS - 1].m, cy, part[0][NT - 1], part[1][NT - 1], part[2][NT - 1]);
+          } else
 #pragma unroll
           for (int tt = 0; tt < NT; ++tt) {
             T pt[D];
@@ -1190,10 +1269,148 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_kernel(const T* __
   }
 }
 
+// ---- K2, float 3D: the streamed form (round 6; what ships for config 3) ---------------------------------------------------
+// The tile form above pays per (group of 16 targets, tile of 2048 sources) for 48 v_readlane (the targets into SGPRs), 48 zeroed
+// partial sums and a transposed reduction (~150 instructions), i.e. 0.5 instructions per pair on top of the pair's fourteen,
+// plus the staging of every tile through LDS behind two block barriers.  Here a WAVE owns one group of 16 targets for its whole
+// source chunk: the targets go into SGPRs once, the 48 partial sums live in registers until the chunk is through, and the wave
+// reduces and adds atomically once.  Sources are the packed (x, y, z, m) records (one coalesced global_load_dwordx4 per 64 sources
+// and 16 pairs per lane, straight from L2 — the 4 MB of config 3 fit every XCD's L2 —: no LDS, no barrier), two batches of KS
+// records per lane in registers, the next one in flight while this one is consumed; the pairs of the whole chunk form ONE
+// software pipeline of k2_pair_step blocks (head of pair p with the tail of pair p - 1, above).  Lanes run along the sources and
+// the wavefront reduction stays what north_star asks of the collapsed variant.
+template <typename T, int D>
+__global__ __launch_bounds__(kBlock) void collapsed_reset_pack_kernel(T* __restrict__ a, const T* __restrict__ ao, uint64_t nelem,
+                                                                      const T* __restrict__ m, const T* __restrict__ x,
+                                                                      src_rec<T, D>* __restrict__ packed, uint32_t sz, uint32_t padded) {
+  const uint64_t e = uint64_t(blockIdx.x) * kBlock + threadIdx.x;
+  if (e < nelem) a[e] = a[e] - ao[e];  // diagonal pairs of the reference (src/all_pairs.h:35-40): a[i] -= ao[i]
+  if (e < padded) {                    // records past the end carry mass 0 at the origin: their pairs add exactly 0
+    src_rec<T, D> r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) r.p[k] = (k < D && e < sz) ? x[e * D + k] : T(0);
+    r.m       = e < sz ? m[e] : T(0);
+    packed[e] = r;
+  }
+}
+
+constexpr int kK2Group = 16;  // targets per wave of the streamed form
+template <int KS>
+__global__ __launch_bounds__(kBlock) void all_pairs_collapsed_stream_kernel(const src_rec<float, 3>* __restrict__ packed,
+                                                                            const float* __restrict__ x, float* __restrict__ a, float c,
+                                                                            uint32_t sz, uint32_t batches_per_chunk, uint32_t nbatches) {
+  using rec_t       = src_rec<float, 3>;
+  constexpr int NT  = kK2Group;
+  const int lane    = threadIdx.x & 63;
+  const uint32_t g  = (blockIdx.x * kWaves + (threadIdx.x >> 6));  // this wave's group of 16 targets
+  const uint32_t i0 = g * NT;
+  if (i0 >= sz) return;  // wave-uniform (no barrier in this kernel)
+  // the group's positions: lane l < 16 loads target i0 + l (body 0's for targets past the end: computed, never stored), then SGPRs
+  float xt[3];
+  {
+    const uint32_t i = (lane < NT && i0 + lane < sz) ? i0 + lane : 0u;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xt[k] = x[uint64_t(i) * 3 + k];
+  }
+  float xg[NT][3];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int k = 0; k < 3; ++k) xg[tt][k] = lane_bcast(xt[k], tt);
+  const uint32_t b0 = blockIdx.y * batches_per_chunk, b1 = min(nbatches, b0 + batches_per_chunk);
+  if (b0 >= b1) return;
+  float part[3][NT];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) part[k][tt] = 0.0f;
+  // batch b = records [b * 64 * KS, (b + 1) * 64 * KS): lane l holds records b * 64 * KS + q * 64 + l, q < KS
+  auto fetch = [&](rec_t (&dst)[KS], uint32_t b) {
+    const rec_t* base = packed + (uint64_t(b) * (64 * KS) + lane);
+#pragma unroll
+    for (int q = 0; q < KS; ++q) dst[q] = base[q * 64];
+  };
+  rec_t cur[KS], nxt[KS];
+  fetch(cur, b0);
+  k2_carry cy = k2_pair_head(cur[0], xg[0]);
+  float mp    = cur[0].m;
+  // one batch against the 16 targets; its first pair's head has been issued already (by the prologue or by the batch before).
+  // (Macros, not lambdas over array references: a pointer to a buffer makes hipcc keep both buffers in scratch memory.)
+#define K2S_CONSUME(SRC)                                                                                       \
+  _Pragma("unroll") for (int p = 1; p < NT * KS; ++p) {                                                        \
+    const int tp = (p - 1) / KS;                                                                               \
+    cy           = k2_pair_step(SRC[p % KS], xg[p / KS], mp, cy, part[0][tp], part[1][tp], part[2][tp]);       \
+    mp           = SRC[p % KS].m;                                                                              \
+  }
+  // the last pair's tail rides on the head of the next batch's first pair
+#define K2S_BRIDGE(NEXT)                                                                                       \
+  cy = k2_pair_step(NEXT[0], xg[0], mp, cy, part[0][NT - 1], part[1][NT - 1], part[2][NT - 1]);                \
+  mp = NEXT[0].m;
+  // two batches per trip so that the two register buffers swap without copies; a chunk is an even number of batches (the host
+  // pads the record array with zero-mass records to that), and the last trip fetches its own second batch again instead of one
+  // past the chunk: the head that rides on the last bridge belongs to no pair and is dropped with the wave
+  for (uint32_t b = b0; b < b1; b += 2) {
+    fetch(nxt, b + 1);
+    K2S_CONSUME(cur)
+    K2S_BRIDGE(nxt)
+    fetch(cur, b + 2 < b1 ? b + 2 : b + 1);
+    K2S_CONSUME(nxt)
+    K2S_BRIDGE(cur)
+  }
+#undef K2S_CONSUME
+#undef K2S_BRIDGE
+  float tot[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) tot[k] = transpose_reduce<float, NT>(part[k], lane);  // lane l: target i0 + l % 16, summed over the wave
+  if (lane < NT && i0 + lane < sz) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) atomicAdd(&a[uint64_t(i0 + lane) * 3 + k], c * tot[k]);
+  }
+}
+
+static int collapsed_stream_launch(const nbody_state* s, hipStream_t st, int ks, uint32_t want_chunks) {
+  using rec_t = src_rec<float, 3>;
+  const uint32_t pair_of_batches = 2u * 64u * uint32_t(ks);  // 1024 records (KS = 8): what ap_scratch_reserve pads a context's buffer to
+  const uint32_t padded = (s->sz + pair_of_batches - 1) / pair_of_batches * pair_of_batches;
+  void* q = nullptr;
+  if (int r = ap_scratch_get(st, 0, sizeof(rec_t) * size_t(padded), &q)) return r;
+  rec_t* packed        = static_cast<rec_t*>(q);
+  const uint64_t nelem = uint64_t(s->sz) * 3;
+  const uint64_t work  = nelem > padded ? nelem : padded;
+  hipLaunchKernelGGL((collapsed_reset_pack_kernel<float, 3>), dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     static_cast<float*>(s->a), static_cast<const float*>(s->ao), nelem, static_cast<const float*>(s->m),
+                     static_cast<const float*>(s->x), packed, s->sz, padded);
+  NB_HIP(hipGetLastError());
+  const uint32_t groups   = (s->sz + kK2Group - 1) / kK2Group;
+  const uint32_t blocks   = (groups + kWaves - 1) / kWaves;
+  const uint32_t nbatches = padded / uint32_t(64 * ks);
+  // chunks: enough waves for >= 16 rounds of the chip's 4096 wave slots where the system allows, whole batches per chunk
+  uint32_t chunks = want_chunks ? want_chunks : (16u * 4096u + groups - 1) / groups;
+  chunks          = std::max(1u, std::min({chunks, nbatches, 65535u}));
+  uint32_t bpc = (nbatches + chunks - 1) / chunks;
+  bpc += bpc & 1u;  // an even number of batches per chunk (nbatches is even)
+  chunks = (nbatches + bpc - 1) / bpc;
+#define NB_K2S(KS)                                                                                                           \
+  hipLaunchKernelGGL((all_pairs_collapsed_stream_kernel<KS>), dim3(blocks, chunks), dim3(kBlock), 0, st, packed,             \
+                     static_cast<const float*>(s->x), static_cast<float*>(s->a), float(s->c), s->sz, bpc, nbatches)
+  if (ks == 4) NB_K2S(4);
+  else NB_K2S(8);
+#undef NB_K2S
+  NB_HIP(hipGetLastError());
+  return NBODY_OK;
+}
+
 template <typename T, int D>
 static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   NB_ARG(s->first == 0 && s->count == s->sz, "all-pairs-collapsed is single-GPU: needs first=0, count=sz");
   if (s->sz == 0) return NBODY_OK;
+  if constexpr (sizeof(T) == 4 && D == 3) {  // float 3D (config 3): the streamed form
+    int form = 20;
+    uint32_t chunks = 0;
+    if (const char* e = experiment_env("NBODY_K2_CFG")) form = atoi(e);  // -DNBODY_EXPERIMENTS builds only (tools/time_collapsed.py)
+    if (const char* e = experiment_env("NBODY_K2_CHUNKS")) chunks = uint32_t(atoi(e));
+    if (form == 20 || form == 21) return collapsed_stream_launch(s, st, form == 20 ? 8 : 4, chunks);
+  }
   uint64_t nelem = uint64_t(s->sz) * D;
   hipLaunchKernelGGL((collapsed_reset_kernel<T, D>), dim3((nelem + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
                      static_cast<T*>(s->a), static_cast<const T*>(s->ao), nelem);
@@ -1218,11 +1435,21 @@ static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   // the fastest at 7.47; with the reciprocal-free weight and a guarded second pass only for the blocks that held a near pair
   // (see the kernel) (8, 8, 1) 6.79, (8, 4, 1) 6.95, (8, 4, 2) 7.00, (8, 2, 2) 7.01, (8, 2, 1) 7.26, (16, 8, 1) 8.03, (8, 4, 4) 9.96.
   int cfg = sizeof(T) == 4 ? 0 : 5;
-  if (const char* e = experiment_env("NBODY_K2_CFG")) cfg = atoi(e);  // -DNBODY_EXPERIMENTS builds only (tools/time_collapsed.py)
+  if (const char* e = experiment_env("NBODY_K2_CFG")) cfg = atoi(e) >= 20 ? cfg : atoi(e);  // -DNBODY_EXPERIMENTS builds only (tools/time_collapsed.py)
 #define NB_K2(NT, KS, NBC)                                                                                              \
   hipLaunchKernelGGL((all_pairs_collapsed_kernel<T, D, NT, KS, NBC>), dim3(iblocks, ysplit), dim3(kBlock), 0, st,        \
                      static_cast<const T*>(s->m), static_cast<const T*>(s->x), static_cast<T*>(s->a), static_cast<T>(s->c), \
                      s->sz, tpb)
+  if constexpr (sizeof(T) == 4 && D == 3) {  // the pair scheduled by hand (k2_pair_step): what ships for float 3D (config 3)
+    switch (cfg) {
+      case 0: NB_K2(16, 8, 0); NB_HIP(hipGetLastError()); return NBODY_OK;
+      case 10: NB_K2(16, 4, 0); NB_HIP(hipGetLastError()); return NBODY_OK;
+      case 11: NB_K2(8, 8, 0); NB_HIP(hipGetLastError()); return NBODY_OK;
+      case 12: NB_K2(8, 4, 0); NB_HIP(hipGetLastError()); return NBODY_OK;
+      case 8: cfg = 0; break;  // experiments: the compiler-scheduled (16, 8, 1), the cross-check of the hand-scheduled form
+      default: break;
+    }
+  }
   switch (cfg) {
     case 0: NB_K2(16, 8, 1); break;
     case 1: NB_K2(8, 4, 4); break;

@@ -1068,8 +1068,9 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
     // The record blocks sit at s[40:71]: the highest SGPR a wave names decides how many waves a SIMD holds, and the steps are NOT
     // where the arithmetic puts them (800 SGPRs, granules of 16): measured with long one-wave blocks that name one high register
-    // (tools/microbench/cu_map.hip, blocks alive at once per SIMD): up to s71 EIGHT, s72 ... s88 seven, s95 and above six — 16 more
-    // SGPRs are held back per wave.  Round 4's first form had the blocks at s[64:95] (six waves, believed seven), its second at
+    // (tools/microbench/cu_map.hip, blocks alive at once per SIMD): up to s73 EIGHT, s74 ... s88 seven, s95 and above six (round 6
+    // measured s72 / s73 / s74: 8 / 8 / 7, profiles/r06/cu_map_microbench.txt) — the granule is 16 SGPRs of a count that includes VCC and
+    // the two reserved pairs (s73 = count 80), and 16 more are held back per wave: floor(800 / (ceil16(count) + 16)).  Round 4's first form had the blocks at s[64:95] (six waves, believed seven), its second at
     // s[48:79] (SEVEN waves — 7168 items alive at once in tools/k9_timeline.py — believed eight); at s[40:71] the kernel's count is
     // 78 with VCC and the reserved pairs and 8192 items are alive at once: config 4 6.38 -> 6.21 ms per traversal, float 4.49 -> 4.31.
 #define K9_REGS3                                                                                                           \

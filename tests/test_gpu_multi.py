@@ -56,26 +56,34 @@ def test_bench_self_launch_forced_dist_matches_plain_run():
     assert 0.2 < plain["roofline"]["frac"] < 0.7
 
 
-def test_bench_line_carries_configs_2_to_4_and_the_handoff_status():
-    """The line the driver records also times BASELINE.json configs[1..3] (after the headline's clock has stopped) with each one's
-    dominant kernel, its average launch time from HIP events, and the fraction of the roofline that bounds it; and K1's chunk
-    hand-off status over the run (no failure; how many waves had to wait)."""
+def test_bench_line_carries_configs_1_to_4_and_the_handoff_status():
+    """The line the driver records also times BASELINE.json configs[0..3] (after the headline's clock has stopped) with each one's
+    dominant kernel, its average launch time from HIP events, and achieved / peak = frac against the roofline that bounds it (one
+    meaning of `frac` in the whole list); config 1 — the one that names the CPU path — carries both legs, the CPU port timed over
+    the whole config; and K1's chunk hand-off status over the run (no failure; how many waves had to wait)."""
     line = _bench({}, "--gpus", "1", "--steps", "1", "--warmup", "1", "--bodies", str(1 << 16), "--no-cpu-baseline")
     assert line["roofline"]["handoff"]["failed"] is False and line["roofline"]["handoff"]["polls"] >= 0
     cfg = line["configs"]
-    assert len(cfg) == 3 and not any("failed" in c for c in cfg), cfg
-    c2, c3, c4 = cfg
+    assert len(cfg) == 4 and not any("failed" in c for c in cfg), cfg
+    c1, c2, c3, c4 = cfg
+    assert "2D float" in c1["workload"] and "10000" in c1["workload"] and c1["bound"] == "valu_fp32", c1
+    assert "all_pairs_force" in c1["kernel"] and 0.1 < c1["frac"] < 0.6 and c1["avg_kernel_ms"] <= c1["ms_per_step"] + 0.01, c1
+    assert c1["cpu_kind"] == "port" and c1["cpu_cores"] >= 1 and c1["cpu_ms_per_step"] > c1["ms_per_step"], c1
     assert "65536" in c2["workload"] and "all_pairs_force_sgpr_kernel<double,3" in c2["kernel"] and c2["bound"] == "valu_fp64"
     assert 0.25 < c2["frac"] < 0.6 and 0.97 * c2["avg_kernel_ms"] <= c2["ms_per_step"] <= c2["avg_kernel_ms"] + 0.08, c2   # the step IS its K1 (+ 40 us; the two are timed over different steps)
     assert c2["handoff"]["failed"] is False
     assert "262144" in c3["workload"] and "collapsed" in c3["kernel"] and c3["bound"] == "valu_fp32" and 0.2 < c3["frac"] < 0.6, c3
     assert c3["avg_kernel_ms"] <= c3["ms_per_step"] * 1.02
-    assert "1000000" in c4["workload"] and "bvh_force_sweep_isa_kernel" in c4["kernel"] and c4["bound"] == "valu_issue", c4
+    if c3["rocprof"]:   # an f32 kernel: rocprofv3's VALUBusy formula is no fraction there and must not be published as one
+        assert c3["rocprof"]["valu_busy_frac"] is None or c3["rocprof"]["valu_busy_frac"] <= 1.0
+    assert "1000000" in c4["workload"] and "bvh_force_sweep_isa_kernel" in c4["kernel"] and c4["bound"] == "valu_fp64", c4
     assert 2e11 < c4["node_tests_per_s"] < 2e12 and 2000 < c4["node_tests_per_body"] < 8000, c4
     assert c4["avg_kernel_ms"] < c4["ms_per_step"] < c4["avg_kernel_ms"] + 1.0
+    assert c4["peak"] == 78.6 and abs(c4["frac"] - c4["achieved"] / c4["peak"]) < 1e-12 and 0.05 < c4["frac"] < 0.4, c4
+    assert c4["valu_issue_frac"] is None or 0.2 < c4["valu_issue_frac"] < 0.8
     assert c4["not_the_bound"]["hbm_cold_bytes_per_s"] > c4["not_the_bound"]["hbm_peak_bytes_per_s"]   # why 8(d)'s HBM model is not the bound
     for c in cfg:
-        assert c["ms_per_step"] > 0 and c["body_steps_per_s"] > 0
+        assert c["ms_per_step"] > 0 and c["body_steps_per_s"] > 0 and abs(c["frac"] - c["achieved"] / c["peak"]) < 1e-12
 
 
 def test_bench_refuses_more_gpus_than_visible():

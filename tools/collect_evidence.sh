@@ -34,7 +34,7 @@ echo "== detailed"; timeout -k 10 400 bash tools/benchmark_detailed.sh 1000 1000
 echo "== PMC K2 / K9"
 C1="SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 C2="SQ_INSTS_SMEM SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_BRANCH SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT"
-PREC=float WL=uniform TAG=pmc_k2 bash tools/pmc_kernel.sh all_pairs_collapsed_kernel all-pairs-collapsed 262144 "$C1" "$C2" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_k2_config3.txt 2>&1
+PREC=float WL=uniform TAG=pmc_k2 bash tools/pmc_kernel.sh all_pairs_collapsed_ all-pairs-collapsed 262144 "$C1" "$C2" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_k2_config3.txt 2>&1
 TAG=pmc_k9 bash tools/pmc_kernel.sh bvh_force_sweep_isa bvh 1000000 "$C1" "$C2" "FETCH_SIZE" "WRITE_SIZE" > $O/pmc_k9_config4.txt 2>&1
 cat $O/pmc_k2_config3.txt $O/pmc_k9_config4.txt
 cd /tmp && export TMPDIR=/tmp

@@ -4,7 +4,8 @@ metadata notes; no GPU needed).  usage: kernel_resources.py [lib.so] [name-filte
 
 Waves per SIMD on gfx950: min(8, by VGPRs, by SGPRs).  VGPRs: 512 per lane and SIMD in the unified file, allocated in blocks of 8,
 accumulation registers included.  SGPRs: 800 per SIMD in granules of 16 with 16 MORE held back per wave — measured, round 5
-(tools/microbench/cu_map.hip: a kernel that names up to s71, sgpr_count <= 78, runs 8 waves per SIMD; up to s88 seven; above six):
+(tools/microbench/cu_map.hip: a kernel that names up to s73, sgpr_count <= 80, runs 8 waves per SIMD — s72 / s73 / s74 measured
+8 / 8 / 7 in round 6 —; up to s88 seven; above six):
 floor(800 / (sgpr_count rounded up to 16 + 16)).  A `*` marks kernels that the SGPRs hold below what their VGPRs allow."""
 import os
 import re

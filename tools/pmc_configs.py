@@ -16,7 +16,7 @@ CONFIGS = {
     "k9_config4": {"kernel": "bvh_force_sweep_isa", "files": ("bvh.hip", "common.hpp"),
                    "args": ["-n", "1000000", "-s", "2", "--algorithm", "bvh", "--workload", "galaxy", "--precision", "double", "--csv-detailed"],
                    "what": "bvh 3D double n = 10^6 galaxy theta = 0.5: one traversal of the initial state"},
-    "k2_config3": {"kernel": "all_pairs_collapsed_kernel", "files": ("all_pairs.hip", "common.hpp"),
+    "k2_config3": {"kernel": "all_pairs_collapsed_", "files": ("all_pairs.hip", "common.hpp"),
                    "args": ["-n", "262144", "-s", "2", "--algorithm", "all-pairs-collapsed", "--workload", "uniform", "--precision", "float", "--csv-detailed"],
                    "what": "all-pairs-collapsed 3D float n = 262144 uniform: one force pass"},
 }

@@ -767,7 +767,11 @@ static int ap_prepare(const nbody_state* s, hipStream_t st, bool pack, src_rec<T
 // Measured (profiles/r05/k1_handoff_cost.txt; f64, us per launch, collected / turns / no protocol at all): N = 2048 16.2 / 23.5 / 15.1,
 // 4096 23 / 41 / 20, 8192 55 / 70 / 51, f32 8192 34 / 76 / 29 — and at 4096 blocks (N = 16 384) 176 / 172 / 172: turns from there on.
 constexpr uint32_t kCollectMaxBlocks = 2048;
-static bool k1_collect(uint32_t target_blocks, uint32_t chunks) { return chunks > 1 && uint64_t(target_blocks) * chunks <= kCollectMaxBlocks; }
+static bool k1_collect(uint32_t target_blocks, uint32_t chunks) {
+  uint32_t limit = kCollectMaxBlocks;
+  if (const char* e = experiment_env("NBODY_K1_COLLECT_MAX")) limit = uint32_t(atoi(e));  // -DNBODY_EXPERIMENTS builds only (tools/tune_small_k1.py)
+  return chunks > 1 && uint64_t(target_blocks) * chunks <= limit;
+}
 template <typename T, int D, int R, int JS>
 static size_t k1_collect_bytes(uint32_t target_blocks, uint32_t chunks) {
   constexpr int TG = kSgprWaves<JS> / JS;

@@ -3,7 +3,7 @@
 # the per-config timings, the reference-shaped benchmark logs + scraped tables, and PMC passes of K2 and K9.
 # Usage (from the repo root on the GPU box): bash tools/collect_evidence.sh r05   (add `short` as a second argument to skip the
 # reference-shaped matrix and the octree / small-tree sets: the parts round 5 did not touch)
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O

@@ -1,7 +1,7 @@
 #!/bin/bash
 # After `gpurun -- bash tools/collect_evidence.sh <tag>`: copy the summaries worth keeping from gpurun_out/ (scratch) into
 # profiles/<tag>/ (tracked).  Usage (in the build container, from the repo root): bash tools/install_evidence.sh r02
-TAG=${1:-r05}
+TAG=${1:-r06}
 S=gpurun_out/$TAG; P=gpurun_out/profiles_$TAG; D=profiles/$TAG
 mkdir -p $D
 for f in bench_n1.json configs_all.json k1_times.json benchmark.log benchmark.csv benchmark_detailed.log benchmark_detailed.csv \

@@ -1372,20 +1372,97 @@ __global__ __launch_bounds__(kBlock) void all_pairs_collapsed_stream_kernel(cons
   }
 }
 
-static int collapsed_stream_launch(const nbody_state* s, hipStream_t st, int ks, uint32_t want_chunks) {
-  using rec_t = src_rec<float, 3>;
-  const uint32_t pair_of_batches = 2u * 64u * uint32_t(ks);  // 1024 records (KS = 8): what ap_scratch_reserve pads a context's buffer to
+// The same shape with the pair left to the compiler (K1's pair_batch: one target from SGPRs against U per-lane sources, the dense
+// rule — K2 has no rule pre-pass): float 2D, and float 3D as the A/B of the hand-scheduled pair.
+template <typename T, int D, int KS>
+__global__ __launch_bounds__(kBlock) void all_pairs_collapsed_stream_cxx_kernel(const src_rec<T, D>* __restrict__ packed,
+                                                                                const T* __restrict__ x, T* __restrict__ a, T c, uint32_t sz,
+                                                                                uint32_t batches_per_chunk, uint32_t nbatches) {
+  using rec_t      = src_rec<T, D>;
+  constexpr int NT = sizeof(T) == 4 ? 16 : 8;
+  constexpr int U  = 64 / int(sizeof(rec_t));  // records per pair_batch call: 4 in float, 2 in double
+  static_assert(KS % U == 0, "whole pair batches");
+  static_assert(sizeof(T) == 4, "float only: see collapsed_dispatch");
+  const int lane    = threadIdx.x & 63;
+  const uint32_t g  = (blockIdx.x * kWaves + (threadIdx.x >> 6));
+  const uint32_t i0 = g * NT;
+  if (i0 >= sz) return;  // wave-uniform (no barrier in this kernel)
+  T xt[D];
+  {
+    const uint32_t i = (lane < NT && i0 + lane < sz) ? i0 + lane : 0u;
+#pragma unroll
+    for (int k = 0; k < D; ++k) xt[k] = x[uint64_t(i) * D + k];
+  }
+  T xg[NT][D];
+#pragma unroll
+  for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+    for (int k = 0; k < D; ++k) xg[tt][k] = lane_bcast(xt[k], tt);
+  const uint32_t b0 = blockIdx.y * batches_per_chunk, b1 = min(nbatches, b0 + batches_per_chunk);
+  if (b0 >= b1) return;
+  const pair_consts<T> pc;
+  T part[D][NT];
+#pragma unroll
+  for (int k = 0; k < D; ++k)
+#pragma unroll
+    for (int tt = 0; tt < NT; ++tt) part[k][tt] = T(0);
+  rec_t cur[KS], nxt[KS];
+#define K2S_FETCH(DST, B)                                                       \
+  {                                                                             \
+    const rec_t* base = packed + (uint64_t(B) * (64 * KS) + lane);              \
+    _Pragma("unroll") for (int q = 0; q < KS; ++q) DST[q] = base[q * 64];       \
+  }
+#define K2S_CONSUME(SRC)                                                                              \
+  _Pragma("unroll") for (int tt = 0; tt < NT; ++tt) {                                                 \
+    T acc1[1][D], xi1[1][D];                                                                          \
+    _Pragma("unroll") for (int k = 0; k < D; ++k) acc1[0][k] = part[k][tt], xi1[0][k] = xg[tt][k];    \
+    _Pragma("unroll") for (int q = 0; q < KS; q += U) {                                               \
+      rec_t su[U];                                                                                    \
+      _Pragma("unroll") for (int u = 0; u < U; ++u) su[u] = SRC[q + u];                               \
+      pair_batch<T, D, 1, U, false>(acc1, xi1, su, pc);                                               \
+    }                                                                                                 \
+    _Pragma("unroll") for (int k = 0; k < D; ++k) part[k][tt] = acc1[0][k];                           \
+  }
+  K2S_FETCH(cur, b0)
+  for (uint32_t b = b0; b < b1; b += 2) {  // an even number of batches per chunk (see the float 3D kernel)
+    K2S_FETCH(nxt, b + 1)
+    K2S_CONSUME(cur)
+    K2S_FETCH(cur, (b + 2 < b1 ? b + 2 : b + 1))
+    K2S_CONSUME(nxt)
+  }
+#undef K2S_FETCH
+#undef K2S_CONSUME
+  T tot[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) tot[k] = transpose_reduce<T, NT>(part[k], lane);  // lane l: target i0 + l % NT, summed over the wave
+  if (lane < NT && i0 + lane < sz) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) atomicAdd(&a[uint64_t(i0 + lane) * D + k], c * tot[k]);
+  }
+}
+
+template <typename T, int D>
+static int collapsed_stream_launch(const nbody_state* s, hipStream_t st, int form, uint32_t want_chunks) {
+  // form: 20 = float 3D with the hand-scheduled pair, 8 records per lane and batch (21: 4); 22 / 23 / 24 = the compiler-scheduled
+  // kernel with 8 / 4 / 2 records per lane and batch
+  using rec_t = src_rec<T, D>;
+  constexpr bool kHand = sizeof(T) == 4 && D == 3;
+  constexpr int NT     = sizeof(T) == 4 ? 16 : 8;
+  constexpr int U      = 64 / int(sizeof(rec_t));
+  int ks = form == 20 || form == 22 ? 8 : (form == 24 ? 2 : 4);
+  if (ks < U) ks = U;
+  const uint32_t pair_of_batches = 2u * 64u * uint32_t(ks);  // at most 1024 records: what ap_scratch_reserve pads a context's buffer to
   const uint32_t padded = (s->sz + pair_of_batches - 1) / pair_of_batches * pair_of_batches;
   void* q = nullptr;
   if (int r = ap_scratch_get(st, 0, sizeof(rec_t) * size_t(padded), &q)) return r;
   rec_t* packed        = static_cast<rec_t*>(q);
-  const uint64_t nelem = uint64_t(s->sz) * 3;
+  const uint64_t nelem = uint64_t(s->sz) * D;
   const uint64_t work  = nelem > padded ? nelem : padded;
-  hipLaunchKernelGGL((collapsed_reset_pack_kernel<float, 3>), dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
-                     static_cast<float*>(s->a), static_cast<const float*>(s->ao), nelem, static_cast<const float*>(s->m),
-                     static_cast<const float*>(s->x), packed, s->sz, padded);
+  hipLaunchKernelGGL((collapsed_reset_pack_kernel<T, D>), dim3((work + kBlock - 1) / kBlock), dim3(kBlock), 0, st,
+                     static_cast<T*>(s->a), static_cast<const T*>(s->ao), nelem, static_cast<const T*>(s->m),
+                     static_cast<const T*>(s->x), packed, s->sz, padded);
   NB_HIP(hipGetLastError());
-  const uint32_t groups   = (s->sz + kK2Group - 1) / kK2Group;
+  const uint32_t groups   = (s->sz + NT - 1) / NT;
   const uint32_t blocks   = (groups + kWaves - 1) / kWaves;
   const uint32_t nbatches = padded / uint32_t(64 * ks);
   // chunks: enough waves for >= 16 rounds of the chip's 4096 wave slots where the system allows, whole batches per chunk
@@ -1394,12 +1471,19 @@ static int collapsed_stream_launch(const nbody_state* s, hipStream_t st, int ks,
   uint32_t bpc = (nbatches + chunks - 1) / chunks;
   bpc += bpc & 1u;  // an even number of batches per chunk (nbatches is even)
   chunks = (nbatches + bpc - 1) / bpc;
-#define NB_K2S(KS)                                                                                                           \
-  hipLaunchKernelGGL((all_pairs_collapsed_stream_kernel<KS>), dim3(blocks, chunks), dim3(kBlock), 0, st, packed,             \
-                     static_cast<const float*>(s->x), static_cast<float*>(s->a), float(s->c), s->sz, bpc, nbatches)
-  if (ks == 4) NB_K2S(4);
-  else NB_K2S(8);
-#undef NB_K2S
+  const dim3 grid(blocks, chunks), block(kBlock);
+  const T* x = static_cast<const T*>(s->x);
+  T* a       = static_cast<T*>(s->a);
+  const T c  = static_cast<T>(s->c);
+  if constexpr (kHand) {
+    if (form == 20) hipLaunchKernelGGL((all_pairs_collapsed_stream_kernel<8>), grid, block, 0, st, packed, x, a, c, s->sz, bpc, nbatches);
+    if (form == 21) hipLaunchKernelGGL((all_pairs_collapsed_stream_kernel<4>), grid, block, 0, st, packed, x, a, c, s->sz, bpc, nbatches);
+  }
+  if (form >= 22 || !kHand) {
+    if (ks == 8) hipLaunchKernelGGL((all_pairs_collapsed_stream_cxx_kernel<T, D, 8>), grid, block, 0, st, packed, x, a, c, s->sz, bpc, nbatches);
+    else if (ks == 4) hipLaunchKernelGGL((all_pairs_collapsed_stream_cxx_kernel<T, D, 4>), grid, block, 0, st, packed, x, a, c, s->sz, bpc, nbatches);
+    else hipLaunchKernelGGL((all_pairs_collapsed_stream_cxx_kernel<T, D, (U <= 2 ? 2 : 4)>), grid, block, 0, st, packed, x, a, c, s->sz, bpc, nbatches);
+  }
   NB_HIP(hipGetLastError());
   return NBODY_OK;
 }
@@ -1408,12 +1492,21 @@ template <typename T, int D>
 static int collapsed_dispatch(const nbody_state* s, hipStream_t st) {
   NB_ARG(s->first == 0 && s->count == s->sz, "all-pairs-collapsed is single-GPU: needs first=0, count=sz");
   if (s->sz == 0) return NBODY_OK;
-  if constexpr (sizeof(T) == 4 && D == 3) {  // float 3D (config 3): the streamed form
-    int form = 20;
+  {
+    // float: the streamed form — 3D (config 3) with the hand-scheduled pair, 2D with the compiled one, 4 records per lane and batch
+    // (N = 10^4 2D: 0.043 ms against the tile form's 0.060, profiles/r06/k2_streamed_form_2.txt); double: the tile form below.
+    // Experiments select the others (tools/time_collapsed.py).
+    int form        = sizeof(T) == 4 ? (D == 3 ? 20 : 23) : -1;
     uint32_t chunks = 0;
-    if (const char* e = experiment_env("NBODY_K2_CFG")) form = atoi(e);  // -DNBODY_EXPERIMENTS builds only (tools/time_collapsed.py)
+    if (const char* e = experiment_env("NBODY_K2_CFG")) form = atoi(e);  // -DNBODY_EXPERIMENTS builds only
     if (const char* e = experiment_env("NBODY_K2_CHUNKS")) chunks = uint32_t(atoi(e));
-    if (form == 20 || form == 21) return collapsed_stream_launch(s, st, form == 20 ? 8 : 4, chunks);
+    // (float only: in double the per-batch near-pair branch of pair_batch under the full unroll over targets x sources makes hipcc keep
+    // every chain's temporaries alive — 264 ... 512 VGPRs and scratch for <double, 3, 2 ... 8> —; double keeps the tile form below)
+    if constexpr (sizeof(T) == 4) {
+      if (form >= 22 && form <= 24) return collapsed_stream_launch<T, D>(s, st, form, chunks);
+      if constexpr (D == 3)
+        if (form == 20 || form == 21) return collapsed_stream_launch<T, D>(s, st, form, chunks);
+    }
   }
   uint64_t nelem = uint64_t(s->sz) * D;
   hipLaunchKernelGGL((collapsed_reset_kernel<T, D>), dim3((nelem + kBlock - 1) / kBlock), dim3(kBlock), 0, st,

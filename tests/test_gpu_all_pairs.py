@@ -398,17 +398,19 @@ def test_collapsed_force_vs_oracle(nb, oracle, dtype, dim):
         dev.close()
 
 
-def test_collapsed_streamed_form_at_its_boundaries(nb, oracle):
-    """Float 3D takes K2's streamed form (round 6: a wave owns 16 targets for its whole source chunk, the packed records come in
-    batches of 512 per wave, two batches per trip, the record array padded with zero-mass records to 1024): sizes on both sides of
-    every boundary of that shape — one body, a group of 16, a wave's 64 lanes, one and two batches, the padding — with a coincident
-    pair, a pair closer than the float epsilon's cube root and the `a - ao` reset, against the oracle's all-pairs sums."""
-    for n in (1, 2, 15, 16, 17, 63, 64, 65, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, 5000, 16385):
-        hs = nb.build_model(0, 3, "uniform", n)
+@pytest.mark.parametrize("dim", [3, 2])
+def test_collapsed_streamed_form_at_its_boundaries(nb, oracle, dim):
+    """Float takes K2's streamed form (round 6: a wave owns 16 targets for its whole source chunk, the packed records come in
+    batches of 512 (3D) / 256 (2D) per wave, two batches per trip, the record array padded with zero-mass records to whole pairs
+    of batches): sizes on both sides of every boundary of that shape — one body, a group of 16, a wave's 64 lanes, one and two
+    batches, the padding — with a coincident pair, a pair closer than the float epsilon's cube root and the `a - ao` reset,
+    against the oracle's all-pairs sums.  3D runs the hand-scheduled pair, 2D the compiled one."""
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 2047, 2049, 5000, 16385):
+        hs = nb.build_model(0, dim, "uniform", n)
         if n >= 17:
             hs.x[5] = hs.x[11]                                  # coincident: contributes exactly 0 (SURVEY 0.7)
             hs.x[7] = hs.x[3] + np.float32(1e-4)                 # r^3 ~ 1e-12 << eps: the `+ eps` dominates the denominator
-        ref = oracle.State(0, 3, n)
+        ref = oracle.State(0, dim, n)
         for k in ("m", "x", "v"):
             getattr(ref, k)[:] = getattr(hs, k)
         ref.dt, ref.c = hs.dt, hs.c

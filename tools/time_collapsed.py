@@ -4,7 +4,7 @@ import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _experiments import load_package
 nb = load_package()
-CFG = {20: "streamed, KS 8 (f32 3D)", 21: "streamed, KS 4 (f32 3D)", 0: "(16,8,hand) f32 3D / (16,8,1)", 8: "(16,8,1)", 10: "(16,4,hand)", 11: "(8,8,hand)", 12: "(8,4,hand)", 1: "(8,4,4)", 2: "(8,4,1)", 3: "(16,8,4)", 4: "(8,4,2)", 5: "(8,8,1)", 6: "(8,2,1)", 7: "(8,2,2)"}
+CFG = {20: "streamed, hand pair, KS 8 (f32 3D)", 21: "streamed, hand pair, KS 4 (f32 3D)", 22: "streamed, compiled pair, KS 8", 23: "streamed, compiled pair, KS 4", 24: "streamed, compiled pair, KS 2", 0: "(16,8,hand) f32 3D / (16,8,1)", 8: "(16,8,1)", 10: "(16,4,hand)", 11: "(8,8,hand)", 12: "(8,4,hand)", 1: "(8,4,4)", 2: "(8,4,1)", 3: "(16,8,4)", 4: "(8,4,2)", 5: "(8,8,1)", 6: "(8,2,1)", 7: "(8,2,2)"}
 SIZES = ((262144, nb.F32, 3), (100000, nb.F64, 3), (100000, nb.F32, 3), (10000, nb.F32, 2))
 for n, dtype, dim in SIZES[:int(os.environ.get("K2_SIZES", "4"))]:
     dev = nb.DeviceSystem.from_host(nb.build_model(dtype, dim, "uniform", n))

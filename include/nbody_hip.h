@@ -115,8 +115,10 @@ int nbody_all_pairs_status(void* stream, uint64_t out[6], int clear);
 /* K2. Replaces all_pairs_collapsed_force (src/all_pairs.h:29-50) with its INTENDED semantics
  * (64-bit pair space, all D components; the reference wraps the pair count at 2^32 and drops
  * component 2 — SURVEY §0.5):  a[i] <- (a[i] - ao[i]) + sum_{j != i} (c*m[j]) * (x[j]-x[i]) / dist3.
- * One lane per ordered pair inside a (target-tile x source-tile) block, wavefront shuffle
- * reduction over the source axis, one atomic add per target per block.  Single-GPU only
+ * Lanes run along the SOURCE axis (one ordered pair per lane and step), the partial sums of 16 (double: 8) targets are
+ * reduced across the wavefront together, one atomic add per target, component and wave (tolerance parity).  Float: a wave
+ * owns its 16 targets for a whole chunk of the packed source records (streamed from L2, no LDS); double: (target group x
+ * LDS source tile) blocks.  Uses the stream's K1 scratch (packed records) like nbody_all_pairs_force.  Single-GPU only
  * (first = 0, count = sz). */
 int nbody_all_pairs_collapsed_force(const nbody_state* s, void* stream);
 

@@ -805,7 +805,15 @@ __global__ __launch_bounds__(1024) void bvh_items_kernel(const uint64_t* __restr
   "v_add_u32_e32 %[cl], %[t2], %[cl]\n\t"                                                                                 \
   "s_mov_b32 %[cinc], 0\n"                                                                                                \
   ".LK9cc" X "%=:\n\t"
+#ifdef NBODY_EXPERIMENTS
+// experiments library: the sweep counts its steps (one scalar add; SCC is free here, K9_COUNT_A compares at the same place) for
+// the timeline tools (tools/k9_timeline.py, tools/k9_duration_carryover.py: is a union's LENGTH a usable start-order predictor?)
+#define K9_NOCOUNT_A(X) "s_add_u32 %[cinc], %[cinc], 1\n\t"
+#define K9_CINC "+s"
+#else
 #define K9_NOCOUNT_A(X) ""
+#define K9_CINC "=&s"
+#endif
 #define K9_COUNT_B "v_add_u32_e32 %[cm], %[cinc], %[cm]\n\t"
 
 // ---- f64 pieces.  R = first SGPR of the record block as a number token pasted by the callers below.
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   // an accepted ROOT is left by the ascend rule with covered + 2^nlevels and level - 1 = 31 after the borrow, which is
   // (sz << 5) - 1 when sz is a power of two; no live key has level 31.
   const uint32_t endk = (sz << 5) - 1u;
-  uint32_t t1, t2, t3, cinc;
+  uint32_t t1, t2, t3, cinc = 0;
   uint64_t match, take, op, sv;
 #define K9_CLOBBER8                                                                                                        \
   "vcc", "scc", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71"
@@ -1060,7 +1068,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     [spA] "+s"(spA), [curB] "=&s"(curB), [offB] "=&s"(offB), [spB] "=&s"(spB), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm),  \
     [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y),              \
     [y2] "=&v"(y2), [e] "=&v"(e), [p] "=&v"(p), [q] "=&v"(q), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3),               \
-    [match] "=&s"(match), [take] "=&s"(take), [op] "=&s"(op), [near] "=&s"(near), [sv] "=&s"(sv), [cinc] "=&s"(cinc)                       \
+    [match] "=&s"(match), [take] "=&s"(take), [op] "=&s"(op), [near] "=&s"(near), [sv] "=&s"(sv), [cinc] K9_CINC(cinc)                       \
   : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [k1875] "s"(pc.k1875), [nearhi] "s"(nearhi),                  \
     [k0375] "s"(k0375), [m52] "s"(m52), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]), [k15] "v"(pc.k15),           \
     [tiny] "v"(tiny), [eps] "v"(eps), [bi] "v"(bi)                                                                         \
@@ -1096,7 +1104,7 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
     [spA] "+s"(spA), [curB] "=&s"(curB), [offB] "=&s"(offB), [spB] "=&s"(spB), [cn] "+v"(cn), [cl] "+v"(cl), [cm] "+v"(cm),  \
     [cb] "+v"(cb), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [r2] "=&v"(r2), [t] "=&v"(t), [y] "=&v"(y),              \
     [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [match] "=&s"(match), [take] "=&s"(take), [op] "=&s"(op),              \
-    [sv] "=&s"(sv), [cinc] "=&s"(cinc)                                                                                                     \
+    [sv] "=&s"(sv), [cinc] K9_CINC(cinc)                                                                                                     \
   : [node] "s"(node), [nlev] "s"(nlevels), [endk] "s"(endk), [xs0] "v"(xs[0]), [xs1] "v"(xs[1]), [xs2] "v"(xs[2]),         \
     [tiny] "s"(tiny), [eps] "s"(eps), [bi] "v"(bi)                                                                         \
   : K9_CLOBBER8
@@ -1128,7 +1136,8 @@ __global__ __launch_bounds__(64) void bvh_force_sweep_isa_kernel(const tree_rec<
   if (g_k9_timeline && threadIdx.x == 0) {
     g_k9_timeline[3 * size_t(blockIdx.x) + 0] = tl_start;
     g_k9_timeline[3 * size_t(blockIdx.x) + 1] = wall_clock64();
-    g_k9_timeline[3 * size_t(blockIdx.x) + 2] = (1ull << 63) | (unsigned long long)(group) | ((unsigned long long)lane_lo << 32) | ((unsigned long long)lane_hi << 40);
+    g_k9_timeline[3 * size_t(blockIdx.x) + 2] = (1ull << 63) | (unsigned long long)(group) | ((unsigned long long)lane_lo << 32) | ((unsigned long long)lane_hi << 40) |
+                                                 ((unsigned long long)(cinc & 0x1ffffu) << 46);  // the sweep's steps (not with counters on)
   }
 #endif
 }

@@ -36,8 +36,9 @@ def timeline():
     group = (tl[:, 2] & np.uint64(0xfffff)).astype(np.int64)
     lo = ((tl[:, 2] >> np.uint64(32)) & np.uint64(63)).astype(np.int64)
     hi = ((tl[:, 2] >> np.uint64(40)) & np.uint64(63)).astype(np.int64)
+    steps = ((tl[:, 2] >> np.uint64(46)) & np.uint64(0x1ffff)).astype(np.int64)   # the sweep's own step count (experiments build)
     t0 = start.min()
-    return group, lo, hi, (start - t0) * 0.01, (end - start) * 0.01
+    return group, lo, hi, (start - t0) * 0.01, (end - start) * 0.01, steps
 
 
 def makespan(dur, order, slots=8192):
@@ -53,9 +54,9 @@ prev = None
 for step in range(3):
     t.bounding_box(st, dev.stream); t.hilbert_sort(st, dev.stream); t.build_tree(st, dev.stream)
     perm = t.read(1, dev.stream).astype(np.int64)            # sorted position -> position before this step's sort
-    g, lo, hi, start, dur = timeline()
+    g, lo, hi, start, dur, steps = timeline()
     if prev is not None:
-        pg, plo, phi, pdur = prev
+        pg, plo, phi, pdur, psteps = prev
         # duration per BODY POSITION of the previous step: every body takes the duration of the item that held it
         body_dur = np.zeros(n)
         for i in range(len(pg)):
@@ -71,12 +72,22 @@ for step in range(3):
               f"longest first by the carried duration {makespan(dur, np.argsort(-carried, kind='stable')):.3f};  "
               f"by the longest carried duration of its bodies {makespan(dur, np.argsort(-carried_max, kind='stable')):.3f};  "
               f"by the true durations {makespan(dur, np.argsort(-dur, kind='stable')):.3f}")
+        # the union's LENGTH (steps of the sweep, counted by the kernel) as the predictor: this step's own, and last step's carried per body
+        body_steps = np.zeros(n)
+        for i in range(len(pg)):
+            body_steps[pg[i] * 64 + plo[i]: min(n, pg[i] * 64 + phi[i] + 1)] = psteps[i]
+        carried_steps = np.array([body_steps[perm[g[i] * 64 + lo[i]: min(n, g[i] * 64 + hi[i] + 1)]].max() for i in range(len(g))])
+        print(f"  steps per item: min {steps.min()} median {int(np.median(steps))} max {steps.max()}; correlation of the duration with the item's own step count "
+              f"{np.corrcoef(steps, dur)[0, 1]:.3f}, with last step's count carried by its bodies {np.corrcoef(carried_steps, dur)[0, 1]:.3f}; "
+              f"own against carried count {np.corrcoef(steps, carried_steps)[0, 1]:.3f}")
+        print(f"  list scheduling, longest first by the own step count {makespan(dur, np.argsort(-steps, kind='stable')):.3f};  by the carried step count "
+              f"{makespan(dur, np.argsort(-carried_steps, kind='stable')):.3f}")
         # how much of a duration is the item and how much the moment it ran at: the same tree traversed twice
-        g2, lo2, hi2, start2, dur2 = timeline()
+        g2, lo2, hi2, start2, dur2, steps2 = timeline()
         same = len(g2) == len(g) and (g2 == g).all() and (lo2 == lo).all()
         dur2 = dur2 if len(dur2) == len(dur) else dur
         print(f"  the SAME tree traversed again: correlation of the two runs' durations {np.corrcoef(dur, dur2)[0, 1]:.3f}" + ("" if same else " (items listed in another order)"))
-    prev = (g, lo, hi, dur)
+    prev = (g, lo, hi, dur, steps)
     dev.sync()
     t.compute_force(st, theta, dev.stream)
     dev.accelerate_step()

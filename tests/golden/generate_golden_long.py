@@ -6,7 +6,8 @@
 
 Every case is 3D double, N = 1024, `--save all --csv-detailed` (exactly `-s` steps, steps + 1 frames and energy pairs:
 /root/reference/src/all_pairs.h:72-83, src/saving.h:100-122, src/system.h:62-79):
-  * 100 steps, galaxy and uniform x {all-pairs, bvh theta 0, bvh theta 0.5}: frames 0, 50, 100 and all 101 (KE, PE) pairs;
+  * 100 steps, galaxy and uniform x {all-pairs, bvh theta 0, bvh theta 0.5, octree theta 0.5 (the reference's default algorithm)}:
+    frames 0, 50, 100 and all 101 (KE, PE) pairs;
   * 1000 steps, galaxy all-pairs: frames 0 and 1000 and all 1001 pairs.
 Beside each case the meta file records how far the reference's OTHER legitimate builds — -Ofast -march=native (its own CPU
 flags, ci/run:112-113) and -O2 -march=native (IEEE operations, FMA contraction) — are from the -O2 build at the same frames /
@@ -48,7 +49,7 @@ def main():
     others = [os.path.join(O.REF_DIR, "nbody_ref_ofast_d3"), os.path.join(O.REF_DIR, "nbody_ref_native_d3")]
     assert os.path.exists(o2) and all(os.path.exists(p) for p in others), "make -C oracle ref ref_ofast"
     cases = [(wl, algo, th, 100, [0, 50, 100]) for wl in ("galaxy", "uniform")
-             for algo, th in (("all-pairs", None), ("bvh", 0.0), ("bvh", 0.5))]
+             for algo, th in (("all-pairs", None), ("bvh", 0.0), ("bvh", 0.5), ("octree", 0.5))]
     cases.append(("galaxy", "all-pairs", None, 1000, [0, 1000]))
     arrays, meta = {}, {}
     for wl, algo, th, steps, keep in cases:

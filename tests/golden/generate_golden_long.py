@@ -8,7 +8,8 @@ Every case is 3D double, N = 1024, `--save all --csv-detailed` (exactly `-s` ste
 /root/reference/src/all_pairs.h:72-83, src/saving.h:100-122, src/system.h:62-79):
   * 100 steps, galaxy and uniform x {all-pairs, bvh theta 0, bvh theta 0.5, octree theta 0.5 (the reference's default algorithm)}:
     frames 0, 50, 100 and all 101 (KE, PE) pairs;
-  * 1000 steps, galaxy all-pairs: frames 0 and 1000 and all 1001 pairs.
+  * 1000 steps, galaxy all-pairs: frames 0 and 1000 and all 1001 pairs;
+  * float (the reference's default precision), galaxy, 100 steps: all-pairs, bvh and octree at theta 0.5.
 Beside each case the meta file records how far the reference's OTHER legitimate builds — -Ofast -march=native (its own CPU
 flags, ci/run:112-113) and -O2 -march=native (IEEE operations, FMA contraction) — are from the -O2 build at the same frames /
 energies, the larger of the two: the yardstick the GPU tests scale their tolerances by.  (-O1 and -O3 produce the -O2 build's
@@ -50,27 +51,30 @@ def main():
     assert os.path.exists(o2) and all(os.path.exists(p) for p in others), "make -C oracle ref ref_ofast"
     cases = [(wl, algo, th, 100, [0, 50, 100]) for wl in ("galaxy", "uniform")
              for algo, th in (("all-pairs", None), ("bvh", 0.0), ("bvh", 0.5), ("octree", 0.5))]
-    cases.append(("galaxy", "all-pairs", None, 1000, [0, 1000]))
+    cases = [c + ("double",) for c in cases]
+    cases.append(("galaxy", "all-pairs", None, 1000, [0, 1000], "double"))
+    # float, the reference's default precision: the galaxy over 100 steps, all-pairs and the two trees at the default angle
+    cases += [("galaxy", algo, th, 100, [0, 50, 100], "float") for algo, th in (("all-pairs", None), ("bvh", 0.5), ("octree", 0.5))]
     arrays, meta = {}, {}
-    for wl, algo, th, steps, keep in cases:
-        name = f"d3_double_{algo}_{wl}_n{N}_s{steps}" + ("" if th is None else f"_th{th}")
-        args = ["-n", N, "-s", steps, "--precision", "double", "--algorithm", algo, "--workload", wl, "--save", "all", "--csv-detailed"]
+    for wl, algo, th, steps, keep, prec in cases:
+        name = f"d3_{prec}_{algo}_{wl}_n{N}_s{steps}" + ("" if th is None else f"_th{th}")
+        args = ["-n", N, "-s", steps, "--precision", prec, "--algorithm", algo, "--workload", wl, "--save", "all", "--csv-detailed"]
         if th is not None:
             args += ["--theta", th]
         f2, e2 = run(o2, args)
         assert f2.shape == (steps + 1, N, 3) and e2.shape == (steps + 1, 2)
         scale = float(np.abs(f2[0]).max())
-        E2 = total(e2)
+        E2 = total(e2.astype(np.float64))
         pos_spread, en_spread = np.zeros(len(keep)), np.zeros(steps + 1)
         for exe in others:   # the larger distance of the two other builds, frame by frame and step by step
             fo, eo = run(exe, args)
-            pos_spread = np.maximum(pos_spread, [np.abs(f2[k] - fo[k]).max() / scale for k in keep])
-            en_spread = np.maximum(en_spread, np.abs(E2 - total(eo)) / np.abs(E2))
+            pos_spread = np.maximum(pos_spread, [np.abs(f2[k].astype(np.float64) - fo[k]).max() / scale for k in keep])
+            en_spread = np.maximum(en_spread, np.abs(E2 - total(eo.astype(np.float64))) / np.abs(E2))
         arrays[name + "__frames"] = f2[keep]
         arrays[name + "__energy"] = e2
         arrays[name + "__build_energy_spread"] = en_spread   # per step, relative, E = KE + PE
         meta[name] = {
-            "dim": 3, "precision": "double", "algorithm": algo, "workload": wl, "n": N, "steps": steps, "theta": th,
+            "dim": 3, "precision": prec, "algorithm": algo, "workload": wl, "n": N, "steps": steps, "theta": th,
             "args": [str(a) for a in args], "frame_ids": keep, "position_scale": scale,
             # max |x_O2 - x_other| / scale at the kept frames, row by row (for bvh every build prints its own sorted order: the
             # spreads are small, so the orders agree)

@@ -15,6 +15,10 @@ Tolerances, each written where it is used:
     edge flips between two legitimate evaluations and moves a force by the node's quadrupole error, so the bound is the larger
     of 1e-11 and 16 x the distance of the reference's own builds at that frame (uniform, step 100: 1.9e-12 => 3.1e-11;
     measured on the product 1.4e-11; galaxy: 3e-15, inside 1e-11; octree uniform: the reference's builds are 4.4e-11 apart => 7e-10);
+  * float (the reference's default precision; galaxy; all-pairs, bvh and octree at theta 0.5): positions within 16 x the distance of
+    the reference's own float builds at that frame (7.6e-7 of the extent at step 50, 2.2e-6 at step 100 => 1.2e-5 / 3.5e-5; the
+    product measures 5.2e-6 at step 50 in all-pairs: its float pair term is within ~4 ulp — rsq and rcp seeds, no polish — where
+    the reference's powf and divide are within ~1.5, so it sits further from either build than they sit from each other), energies 2e-4;
   * energies, every step of the 100: rel 1e-11 of |E| per component pair;
   * accumulated drift: the total energy E = KE + PE of the product against the reference's, relative, at steps 100 / 300 / 1000 of
     the 1000-step run: <= 10 x the LARGEST distance of the reference's own other builds from -O2 at the same step, but no tighter
@@ -47,9 +51,10 @@ def test_positions_and_energies_after_100_steps_vs_reference(nb, golden_long_run
     for name, case in meta.items():
         if case["steps"] != 100:
             continue
-        ref, ref_en = data[name + "__frames"], data[name + "__energy"]
+        dbl = case["precision"] == "double"
+        ref, ref_en = data[name + "__frames"], data[name + "__energy"].astype(np.float64)
         keep = {fid: k for k, fid in enumerate(case["frame_ids"])}
-        dev = nb.DeviceSystem.from_host(nb.build_model(1, 3, case["workload"], case["n"]))
+        dev = nb.DeviceSystem.from_host(nb.build_model(1 if dbl else 0, 3, case["workload"], case["n"]))
         scale = case["position_scale"]
         theta = case["theta"] if case["theta"] is not None else 0.5
         assert np.array_equal(dev.download().x, ref[keep[0]]), name
@@ -59,25 +64,28 @@ def test_positions_and_energies_after_100_steps_vs_reference(nb, golden_long_run
             nb.run(dev, case["algorithm"], 1, theta)
             en.append(dev.calc_energies())
             if step in keep:
-                x = dev.download().x
-                want = ref[keep[step]]
+                x = dev.download().x.astype(np.float64)
+                want = ref[keep[step]].astype(np.float64)
                 tol = POS_TOL
                 if case["algorithm"] in ("bvh", "octree") and theta > 0:
                     tol = max(POS_TOL, 16 * case["build_position_spread"][keep[step]])
+                if not dbl:   # float: 16 x what the reference's own builds are apart at this frame (see the header)
+                    tol = 16 * case["build_position_spread"][keep[step]]
                 if case["algorithm"] == "bvh":
                     assert_frames_equal_as_multisets(x, want, tol)
                 err = np.abs(x - want).max() / scale
-                worst = max(worst, err)
+                worst = max(worst, err / tol)
                 assert err <= tol, (name, step, err, tol)
         en = np.array(en, dtype=np.float64)
         en_err = np.abs(en - ref_en).max(axis=0) / np.abs(ref_en).max(axis=0)
-        assert en_err.max() <= EN_TOL, (name, en_err)
+        # float energies: the reference's (and the oracle's) serial float accumulator carries ~1e-4 itself (test_calc_energies_vs_oracle)
+        assert en_err.max() <= (EN_TOL if dbl else 2e-4), (name, en_err)
         report.append((name, worst, en_err.max(), case["build_position_spread"][-1]))
         dev.close()
         ran += 1
-    assert ran == 8
+    assert ran == 11
     for r in report:
-        print("%-48s positions %.2e  energies %.2e  (the reference's own builds at step 100: %.2e)" % r)
+        print("%-48s positions %.2f of their tolerance  energies %.2e  (the reference's own builds at step 100: %.2e)" % r)
 
 
 def test_energy_drift_over_1000_steps_vs_reference(nb, golden_long_runs):

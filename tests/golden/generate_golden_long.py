@@ -9,7 +9,8 @@ Every case is 3D double, N = 1024, `--save all --csv-detailed` (exactly `-s` ste
   * 100 steps, galaxy and uniform x {all-pairs, bvh theta 0, bvh theta 0.5, octree theta 0.5 (the reference's default algorithm)}:
     frames 0, 50, 100 and all 101 (KE, PE) pairs;
   * 1000 steps, galaxy all-pairs: frames 0 and 1000 and all 1001 pairs;
-  * float (the reference's default precision), galaxy, 100 steps: all-pairs, bvh and octree at theta 0.5.
+  * float (the reference's default precision), galaxy, 100 steps: all-pairs, bvh and octree at theta 0.5;
+  * 2D double, galaxy, 100 steps: the same three (yardstick: the -Ofast build alone).
 Beside each case the meta file records how far the reference's OTHER legitimate builds — -Ofast -march=native (its own CPU
 flags, ci/run:112-113) and -O2 -march=native (IEEE operations, FMA contraction) — are from the -O2 build at the same frames /
 energies, the larger of the two: the yardstick the GPU tests scale their tolerances by.  (-O1 and -O3 produce the -O2 build's
@@ -55,14 +56,19 @@ def main():
     cases.append(("galaxy", "all-pairs", None, 1000, [0, 1000], "double"))
     # float, the reference's default precision: the galaxy over 100 steps, all-pairs and the two trees at the default angle
     cases += [("galaxy", algo, th, 100, [0, 50, 100], "float") for algo, th in (("all-pairs", None), ("bvh", 0.5), ("octree", 0.5))]
+    cases = [c + (3,) for c in cases]
+    # 2D double (the reference is built once per dimension): the galaxy over 100 steps, frames 0 and 100
+    cases += [("galaxy", algo, th, 100, [0, 100], "double", 2) for algo, th in (("all-pairs", None), ("bvh", 0.5), ("octree", 0.5))]
     arrays, meta = {}, {}
-    for wl, algo, th, steps, keep, prec in cases:
-        name = f"d3_{prec}_{algo}_{wl}_n{N}_s{steps}" + ("" if th is None else f"_th{th}")
+    for wl, algo, th, steps, keep, prec, dim in cases:
+        o2 = os.path.join(O.REF_DIR, f"nbody_ref_d{dim}")
+        others = [os.path.join(O.REF_DIR, f"nbody_ref_ofast_d{dim}")] + ([os.path.join(O.REF_DIR, "nbody_ref_native_d3")] if dim == 3 else [])
+        name = f"d{dim}_{prec}_{algo}_{wl}_n{N}_s{steps}" + ("" if th is None else f"_th{th}")
         args = ["-n", N, "-s", steps, "--precision", prec, "--algorithm", algo, "--workload", wl, "--save", "all", "--csv-detailed"]
         if th is not None:
             args += ["--theta", th]
         f2, e2 = run(o2, args)
-        assert f2.shape == (steps + 1, N, 3) and e2.shape == (steps + 1, 2)
+        assert f2.shape == (steps + 1, N, dim) and e2.shape == (steps + 1, 2)
         scale = float(np.abs(f2[0]).max())
         E2 = total(e2.astype(np.float64))
         pos_spread, en_spread = np.zeros(len(keep)), np.zeros(steps + 1)
@@ -74,7 +80,7 @@ def main():
         arrays[name + "__energy"] = e2
         arrays[name + "__build_energy_spread"] = en_spread   # per step, relative, E = KE + PE
         meta[name] = {
-            "dim": 3, "precision": prec, "algorithm": algo, "workload": wl, "n": N, "steps": steps, "theta": th,
+            "dim": dim, "precision": prec, "algorithm": algo, "workload": wl, "n": N, "steps": steps, "theta": th,
             "args": [str(a) for a in args], "frame_ids": keep, "position_scale": scale,
             # max |x_O2 - x_other| / scale at the kept frames, row by row (for bvh every build prints its own sorted order: the
             # spreads are small, so the orders agree)

@@ -152,13 +152,14 @@ def test_bvh_key_ties_match_the_reference_as_multisets(oracle, golden_bvh_ties):
 
 def test_long_runs_bit_exact(oracle, golden_long_runs):
     """SURVEY §8(c) at its stated length: 100 steps at N = 1024 (3D double; galaxy and uniform; all-pairs, bvh theta 0 and 0.5, octree
-    theta 0.5), the galaxy in float (the reference's default precision: all-pairs, bvh and octree at theta 0.5), and one 1000-step
+    theta 0.5), the galaxy in float (the reference's default precision) and in 2D double (all-pairs, bvh and octree at theta 0.5
+    each), and one 1000-step
     all-pairs run that goes through the discs' collision (energy jumps by 5e5 at step 366): the oracle holds the reference's
     frames AND every (KE, PE) pair bit for bit (reference: src/all_pairs.h:72-83, src/saving.h:100-122, src/system.h:62-79)."""
     meta, data = golden_long_runs
-    assert len(meta) == 12
+    assert len(meta) == 15
     for name, case in meta.items():
-        s = oracle.build_model(DT[case["precision"]], 3, case["workload"], case["n"])
+        s = oracle.build_model(DT[case["precision"]], case["dim"], case["workload"], case["n"])
         ref, ref_en = data[name + "__frames"], data[name + "__energy"]
         keep = {fid: k for k, fid in enumerate(case["frame_ids"])}
         assert ref.dtype == s.x.dtype and np.array_equal(s.x, ref[keep[0]]), name
